@@ -40,6 +40,7 @@ class _BicycleBase:
     """Shared plumbing: engines are cached per (params, Ts, centerline size, cost)."""
     MODEL_ID = None
     NX = None
+    CLIP_INPUTS = 0     # whether the RHS clips d, delta to the actuator limits first
 
     def __init__(self):
         self.params = DEFAULT_PARAMS.copy()  # numeric stand-in for the reference's symbolic vector
@@ -58,7 +59,8 @@ class _BicycleBase:
         eng = self._engines.get(key)
         if eng is None:
             cfg = _lib.default_config(self.MODEL_ID, int(N), S=int(S), Ts=float(self.Ts), veh=list(p),
-                                      v_ref=float(v_ref), cost_w=list(cw), wrap_mode=int(wrap_mode))
+                                      v_ref=float(v_ref), cost_w=list(cw), wrap_mode=int(wrap_mode),
+                                      clip_inputs=int(self.CLIP_INPUTS))
             eng = BatchedMPC(cfg, _dev())
             self._engines[key] = eng
         return eng
@@ -133,12 +135,16 @@ class _BicycleBase:
 
 
 class KinematicBicyclePacejka(_BicycleBase):
-    """car_dynamics.py:9 -- state [x, y, phi, vx, vy, omega], input [d, delta]."""
+    """car_dynamics.py:9 -- state [x, y, phi, vx, vy, omega], input [d, delta].  The CasADi RHS of
+    car_dynamics.py:93-129 uses the inputs as they come (no clipping)."""
     MODEL_ID = _lib.MODEL_PACEJKA
     NX = 6
+    CLIP_INPUTS = 0
 
 
 class KinematicBicycleSimplified(_BicycleBase):
-    """dynamics.py:122 -- state [x, y, phi, v], input [d, delta]."""
+    """dynamics.py:122 -- state [x, y, phi, v], input [d, delta].  dynamics.py:163 clips d and delta
+    to the actuator limits inside the RHS, so this mirror's engines do too."""
     MODEL_ID = _lib.MODEL_KINEMATIC
     NX = 4
+    CLIP_INPUTS = 1

@@ -115,6 +115,21 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     if (c.model != MPC_MODEL_KINEMATIC && c.model != MPC_MODEL_PACEJKA) return fail(MPC_E_ARG, "unknown model");
     if (c.constr_mode < 0 || c.constr_mode > 2) return fail(MPC_E_ARG, "unknown constr_mode");
     if (c.max_no_progress < 1) return fail(MPC_E_ARG, "max_no_progress must be >= 1");
+    if (c.max_iter < 1 || c.max_outer < 1 || c.max_total_inner < 1 || c.max_total_evals < 0)
+        return fail(MPC_E_ARG, "max_iter, max_outer, max_total_inner must be >= 1 and max_total_evals >= 0");
+    if (c.max_num_initial_retries < 0 || c.max_num_retries < 0 || c.max_total_num_retries < 0)
+        return fail(MPC_E_ARG, "retry limits must be >= 0");
+    if (!(c.Ts > 0.0) || !std::isfinite(c.Ts)) return fail(MPC_E_ARG, "Ts must be positive and finite");
+    // alpaqa has a separate initial-penalty path for Sigma_0 == 0; it is not restated here
+    if (!(c.Sigma0 > 0.0) || !(c.Sigma_max >= c.Sigma0) || !(c.M >= 0.0))
+        return fail(MPC_E_ARG, "need 0 < Sigma0 <= Sigma_max and M >= 0");
+    if (!(c.L_min > 0.0) || !(c.L_min <= c.L_max)) return fail(MPC_E_ARG, "need 0 < L_min <= L_max");
+    if (!(c.alm_eps > 0.0) || !(c.alm_delta > 0.0) || !(c.eps0 > 0.0))
+        return fail(MPC_E_ARG, "tolerances alm_eps, alm_delta, eps0 must be positive");
+    if (!(c.tau_min > 0.0) || !(c.tau_min <= 1.0)) return fail(MPC_E_ARG, "tau_min must be in (0, 1]");
+    if (!(c.Lgamma_factor > 0.0) || !(c.Lgamma_factor < 1.0)) return fail(MPC_E_ARG, "Lgamma_factor must be in (0, 1)");
+    for (int i = 0; i < 2; i++)
+        if (!(c.u_lb[i] <= c.u_ub[i])) return fail(MPC_E_ARG, "input box: u_lb must not exceed u_ub");
     std::memset(&d, 0, sizeof d);
     d.model = c.model; d.N = c.N; d.S = c.S; d.nfe = c.nfe; d.wrap_mode = c.wrap_mode;
     d.clip_inputs = c.clip_inputs; d.constr_mode = c.constr_mode; d.sm = stage_m(&c);
@@ -498,7 +513,17 @@ static Workspace group_view(const Workspace &w, const DevCfg &c, int g, int lo, 
 }
 
 // the solve proper; x0 / U / lambda are the caller's buffers, used in place
+static int run_solver_rounds(mpc_handle *h, hipStream_t s);
 static int run_solver(mpc_handle *h, hipStream_t s)
+{
+    const int rc = run_solver_rounds(h, s);
+    // On any failure rounds may still be queued on the sub-batch streams (non-blocking streams: a
+    // wait on `s` does not cover them) and they write into the caller's U / lambda and the arena:
+    // nothing is handed back to the caller before the device has drained.
+    if (rc != MPC_OK) (void)hipDeviceSynchronize();
+    return rc;
+}
+static int run_solver_rounds(mpc_handle *h, hipStream_t s)
 {
     const DevCfg &c = h->dc;
     Workspace &w = h->ws;
@@ -559,7 +584,10 @@ static int run_solver(mpc_handle *h, hipStream_t s)
             int *counts_next = v.counts + (cur ^ 1) * 4;
             hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             // profile mode samples every 8th round: five events per sampled launch set
-            if (h->profile && (round & 7) == 0) for (int k = 0; k < 5; k++) ev[k] = get_event(h, nev++);
+            if (h->profile && (round & 7) == 0 && get_event(h, nev + 4)) { // all five exist, or none is used
+                for (int k = 0; k < 5; k++) ev[k] = h->ev_pool[nev + k];
+                nev += 5;
+            }
             if (ev[0]) (void)hipEventRecord(ev[0], gs[g]);
             launch_step(h, v, gs[g], lists, counts, counts_next);
             if (ev[1]) (void)hipEventRecord(ev[1], gs[g]);
@@ -695,10 +723,10 @@ extern "C" int mpc_last_speculation(mpc_handle *h, int64_t *issued, int64_t *use
     return MPC_OK;
 }
 
-extern "C" int mpc_last_solve_info2(mpc_handle *h, double *lbfgs_ms, int64_t *lbfgs_rows)
+extern "C" int mpc_last_solve_info2(mpc_handle *h, double *launch_pairs, int64_t *lbfgs_rows)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_solve_info2: null handle");
-    if (lbfgs_ms) *lbfgs_ms = (double)h->launches; // number of (step, eval) launch pairs of the last solve
+    if (launch_pairs) *launch_pairs = (double)h->launches; // (step, eval) launch sets of the last solve
     if (lbfgs_rows) *lbfgs_rows = h->lbfgs_rows;
     return MPC_OK;
 }

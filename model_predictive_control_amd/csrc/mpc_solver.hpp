@@ -212,8 +212,12 @@ __device__ __forceinline__ void strow(double *__restrict__ p, int n, int lane, c
 
 __device__ __forceinline__ double prox_p(const DevCfg &c, int par, double x, double g, double gamma)
 {
-    const double lb = c.u_lb[par], ub = c.u_ub[par];
-    return fmin(fmax(-gamma * g, lb - x), ub - x);
+    // comparison-selects, not fmin/fmax: a NaN gradient must stay a NaN step (Eigen's cwiseMax/cwiseMin
+    // in alpaqa's projection keep it too), so that ||p||/gamma is NaN and the stop test says NotFinite
+    const double lo = c.u_lb[par] - x, hi = c.u_ub[par] - x;
+    double p = -gamma * g;
+    p = p < lo ? lo : p;
+    return hi < p ? hi : p;
 }
 __device__ __forceinline__ bool in_J(const DevCfg &c, int par, double x, double g, double gamma)
 {
@@ -568,9 +572,10 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             G = g;
             strow<NE>(w.gk + an, n, lane, g);
             const double dn2 = wave_sum(s);
-            Lk = sqrt(dn2) / sqrt(hn2);
-            Lk = fmin(fmax(Lk, c.L_min), c.L_max);
-            if (!isfinite(Lk)) {
+            // std::clamp semantics: a NaN estimate stays NaN (fmin/fmax would turn it into L_min)
+            const double L0 = sqrt(dn2) / sqrt(hn2);
+            Lk = L0 < c.L_min ? c.L_min : (c.L_max < L0 ? c.L_max : L0);
+            if (!isfinite(Lk) || psik != psik) {
                 ps_status = ST_NOTFINITE; ps_iters = 0; ps_eps = INFINITY;
                 phase = PH_INNER_EXIT; break;
             }
@@ -643,7 +648,9 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                            : !isfinite(epsk) ? ST_NOTFINITE
                            : noprog > c.max_no_progress ? ST_NOPROGRESS : ST_UNKNOWN;
             if (stop != ST_UNKNOWN) {
-                if (stop == ST_CONVERGED || overwrite) {
+                // (deviation, for the caller's safety: a NotFinite inner solve never hands back its iterate;
+                // alpaqa would move a NaN xhat into x when always_overwrite_results is set)
+                if (stop == ST_CONVERGED || (overwrite && stop != ST_NOTFINITE)) {
                     // x <- xhat, y <- yhat(xhat), err_z = g(xhat) - Pi_D(g(xhat) + y/Sigma)
                     Row<NE> x = X;
                     const Row<NE> g = G;
@@ -832,6 +839,20 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             const int conv = ps_status == ST_CONVERGED;
             inner_fail += !conv;
             inner_tot += ps_iters;
+            if (ps_status == ST_NOTFINITE && ps_iters == 0) {
+                // psi or its gradient is non-finite AT the point the inner solve starts from: no penalty
+                // or tolerance change repairs that, the solve ends here with the inner status (a failure
+                // at controller.py:64), U untouched.  alpaqa 0.0.1 would walk through its retries, two
+                // evaluations each, and end as MaxIter after max_outer of them -- a 2000-round straggler
+                // for the whole batch.  A NotFinite that shows up later in an inner solve (a line-search
+                // trial that overflowed and was accepted because NaN compares false, as in alpaqa) takes
+                // the ordinary not-converged path below.
+                out_eps = ps_eps; out_delta = ne1;
+                status = ST_NOTFINITE;
+                outer += 1;
+                phase = PH_DONE;
+                break;
+            }
             const int out_of_time = inner_tot >= c.max_total_inner ||
                                     (c.max_total_evals > 0 && nevals >= c.max_total_evals);
             const int backtrack = !conv && !overwrite && !out_of_time;
@@ -852,9 +873,10 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                 for (int kk = lane; kk < m; kk += 64) { // error2.swap(error1); ne1 = ||error1||_inf
                     const double t = w.e1[am + kk], e = w.e2[am + kk];
                     w.e1[am + kk] = e; w.e2[am + kk] = t;
-                    mx = fmax(mx, fabs(e));
+                    const double ae = fabs(e);
+                    mx = (ae > mx || ae != ae) ? ae : mx;   // NaN-propagating max
                 }
-                ne1 = wave_max(mx);
+                ne1 = __ballot(mx != mx) != 0ull ? NAN : wave_max(mx);
                 const int alm_conv = ps_eps <= c.alm_eps && conv && ne1 <= c.alm_delta;
                 if (alm_conv || out_of_iter || out_of_time) {
                     out_eps = ps_eps; out_delta = ne1;

@@ -478,7 +478,11 @@ static void calc_xhat(const prob_t *P, double gamma, const double *x, const doub
 {
     for (int i = 0; i < P->n; i++) {
         double lb = P->c->u_lb[i & 1], ub = P->c->u_ub[i & 1];
-        double pi = fmin(fmax(-gamma * g[i], lb - x[i]), ub - x[i]);
+        /* comparison-selects keep a NaN gradient a NaN step (as Eigen's cwiseMax/cwiseMin do) */
+        double lo = lb - x[i], hi = ub - x[i];
+        double pi = -gamma * g[i];
+        pi = pi < lo ? lo : pi;
+        pi = hi < pi ? hi : pi;
         p[i] = pi; xh[i] = x[i] + pi;
     }
 }
@@ -614,8 +618,9 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
     double dn2 = 0;
     for (int i = 0; i < n; i++) { double d = gn[i] - gk[i]; dn2 += d * d; }
     double Lk = sqrt(dn2) / sqrt(hn2);
-    Lk = fmin(fmax(Lk, c->L_min), c->L_max);
-    if (!isfinite(Lk)) { st.status = ORC_ST_NOTFINITE; return st; }
+    /* std::clamp: NaN stays NaN */
+    Lk = Lk < c->L_min ? c->L_min : (c->L_max < Lk ? c->L_max : Lk);
+    if (!isfinite(Lk) || psik != psik) { st.status = ORC_ST_NOTFINITE; return st; }
     double gamma = c->Lgamma_factor / Lk;
     double tau = NAN;
 
@@ -656,7 +661,9 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
                  : !isfinite(epsk) ? ORC_ST_NOTFINITE
                  : no_progress > c->max_no_progress ? ORC_ST_NOPROGRESS : ORC_ST_UNKNOWN;
         if (stop != ORC_ST_UNKNOWN) {
-            if (stop == ORC_ST_CONVERGED || always_overwrite) {
+            /* (deviation, for the caller's safety: a NotFinite inner solve never hands back its
+             * iterate -- alpaqa would move a NaN x-hat into x when always_overwrite is set) */
+            if (stop == ORC_ST_CONVERGED || (always_overwrite && stop != ORC_ST_NOTFINITE)) {
                 if (m) {
                     /* calc_err_z: g(xh) - Pi_D(g(xh) + Sigma^-1 y) */
                     orc_constraints(c, P->x0, P->cl, xh, err_z);
@@ -765,11 +772,25 @@ static void update_penalty(const orc_config *c, double Delta, int first, const d
 
 static double norm_inf(const double *v, int m)
 {
-    double r = 0; for (int i = 0; i < m; i++) r = fmax(r, fabs(v[i])); return r;
+    double r = 0;
+    for (int i = 0; i < m; i++) { double a = fabs(v[i]); if (a > r || a != a) r = a; if (r != r) break; }
+    return r; /* NaN-propagating */
 }
 
 /* a-8: alpaqa ALMSolver::operator() with controller.py:39-48 parameters; wall-clock
  * caps (controller.py:30,:44) replaced by iteration caps (deliberate deviation). */
+/* optional per-outer-iteration trace (test / study aid): rows of ORC_TRACE_COLS doubles */
+static __thread double *g_trace = NULL;
+static __thread int g_trace_rows = 0, g_trace_n = 0;
+int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
+                     double *stats, double *trace, int max_rows)
+{
+    g_trace = trace; g_trace_rows = max_rows; g_trace_n = 0;
+    orc_solve(c, x0, cl, U, lam, stats);
+    g_trace = NULL;
+    return g_trace_n;
+}
+
 void orc_solve(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                double *stats)
 {
@@ -814,9 +835,27 @@ void orc_solve(const orc_config *c, const double *x0, const double *cl, double *
         if (ps.wrote) out_psi = ps.psi_hat;
         inner_fail += !conv;
         inner_it += ps.iters;
+        if (ps.status == ORC_ST_NOTFINITE && ps.iters == 0) {
+            /* psi or its gradient is non-finite AT the point the inner solve starts from: no penalty or
+             * tolerance change repairs that, the solve ends with the inner status (deliberate: alpaqa
+             * 0.0.1 would walk through its retries, two evaluations each, and end as MaxIter after
+             * max_outer of them; controller.py:64 counts either as a failure).  A NotFinite that shows
+             * up LATER in an inner solve (a line-search trial that overflowed and was accepted because
+             * NaN compares false, as in alpaqa) takes the ordinary not-converged path below. */
+            out_eps = ps.eps; out_delta = ne1; outer = i + 1; status = ORC_ST_NOTFINITE;
+            break;
+        }
         int out_of_time = inner_it >= c->max_total_inner ||
                           (c->max_total_evals > 0 && P.n_evals >= c->max_total_evals);
         int backtrack = !conv && !overwrite && !out_of_time;
+        if (g_trace && g_trace_n < g_trace_rows) {
+            double *t = g_trace + (size_t)g_trace_n++ * ORC_TRACE_COLS;
+            double smin = INFINITY, smax = 0;
+            for (int k = 0; k < m; k++) { smin = fmin(smin, Sig[k]); smax = fmax(smax, Sig[k]); }
+            t[0] = i; t[1] = eps; t[2] = ps.status; t[3] = ps.iters; t[4] = ps.eps;
+            t[5] = ps.wrote ? norm_inf(e2, m) : NAN; t[6] = smin; t[7] = smax; t[8] = backtrack;
+            t[9] = overwrite; t[10] = (double)P.n_evals; t[11] = norm_inf(lam, m);
+        }
         if (backtrack) {
             if (!first) {
                 Delta = fmax(1.0, Delta * c->Delta_lower);

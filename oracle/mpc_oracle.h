@@ -98,6 +98,14 @@ double orc_psi(const orc_config *c, const double *x0, const double *cl, const do
 void orc_solve(const orc_config *c, const double *x0, const double *cl,
                double *U, double *lam, double *stats);
 
+/* the same, recording one row per ALM outer iteration into trace[max_rows][ORC_TRACE_COLS]:
+ * [outer, eps asked, inner status, inner iterations, eps reached, ||err_z||_inf (NaN: iterate not
+ * handed back), min Sigma, max Sigma, backtrack, overwrite, evaluations so far, ||lambda||_inf];
+ * returns the number of rows written */
+#define ORC_TRACE_COLS 12
+int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
+                     double *stats, double *trace, int max_rows);
+
 /* batch: x0 [B][nx], cl table [C][2S], cl_index [B] (NULL -> all 0), U [B][n], lam [B][m] */
 void orc_solve_batch(const orc_config *c, int B, const double *x0, const double *cl,
                      const int32_t *cl_index, double *U, double *lam, double *stats,

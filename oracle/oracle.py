@@ -75,6 +75,7 @@ def lib():
         L.orc_constraints.argtypes = [cp, dp, dp, dp, dp]
         L.orc_psi.argtypes = [cp, dp, dp, dp, dp, dp, dp, dp]; L.orc_psi.restype = C.c_double
         L.orc_solve.argtypes = [cp, dp, dp, dp, dp, dp]
+        L.orc_solve_traced.argtypes = [cp, dp, dp, dp, dp, dp, dp, C.c_int]; L.orc_solve_traced.restype = C.c_int
         L.orc_solve_batch.argtypes = [cp, C.c_int, dp, dp, ip, dp, dp, dp, C.c_int]
         L.orc_psi_batch.argtypes = [cp, C.c_int, dp, dp, ip, dp, dp, dp, dp, dp, C.c_int]
         L.orc_max_threads.restype = C.c_int
@@ -178,6 +179,22 @@ def solve(cfg, x0, cl, U0, lam0=None):
     st = np.empty(NSTATS)
     lib().orc_solve(C.byref(cfg), _d(x0), _d(cl), _d(U), _d(lam), _d(st))
     return U, lam[:mm], st
+
+
+TRACE_COLS = ["outer", "eps_asked", "inner_status", "inner_iters", "eps_reached", "err_z_inf", "Sigma_min",
+              "Sigma_max", "backtrack", "overwrite", "evals", "lambda_inf"]
+
+
+def solve_traced(cfg, x0, cl, U0, lam0=None, max_rows=256):
+    """solve() plus one trace row per ALM outer iteration (columns: TRACE_COLS)."""
+    x0, cl = _f64(x0), _f64(cl)
+    U = _f64(U0).copy()
+    mm = m(cfg)
+    lam = np.zeros(max(mm, 1)) if lam0 is None else _f64(lam0).copy()
+    st = np.empty(NSTATS)
+    tr = np.zeros((max_rows, len(TRACE_COLS)))
+    k = lib().orc_solve_traced(C.byref(cfg), _d(x0), _d(cl), _d(U), _d(lam), _d(st), _d(tr), max_rows)
+    return U, lam[:mm], st, tr[:k]
 
 
 def solve_batch(cfg, x0, cl, U0, lam0=None, cl_index=None, nthreads=0):
