@@ -160,6 +160,14 @@ int mpc_last_speculation(mpc_handle *h, int64_t *issued, int64_t *used);
 /* profile mode: summed HIP-event durations (ms) of the last solve's kernels,
  * out4 = [step_kernel, rollout_kernel (K1a), stage_kernel (K1b), adjoint_kernel (K1c)] */
 int mpc_last_kernel_ms(mpc_handle *h, double *out4);
+/* the same with the persistent kernel and the launch counts: ms5 / launches5 = [step_kernel, K1a rollout
+ * (either kernel), K1b stage (or fused K1b+K1c), K1c adjoint (unfused launches only), solo_kernel];
+ * solo_agents = agents that finished in the persistent wave-per-agent kernel.  Any pointer may be NULL. */
+int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int64_t *solo_agents);
+/* A sub-batch group whose round holds at most `max_requests` evaluation requests leaves the rounds
+ * and finishes in the persistent wave-per-agent kernel; batches up to that size use it from the
+ * start (0 = rounds only; default 1024, environment MPC_SOLO_MAX).  Results do not depend on it. */
+int mpc_set_solo_max(mpc_handle *h, int max_requests);
 /* sub-batch pipelining: the batch is split into `groups` contiguous ranges whose rounds run on
  * separate HIP streams (0 = automatic: 3 from 24576 agents, 2 from 16384, else 1; at most 8) */
 int mpc_set_groups(mpc_handle *h, int groups);

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPC_LIB_PATH", os.path.join(_HERE, "libmpc_hip.so"))  # override: dev experiments
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("mpc_api.hip", "mpc_aux.hpp", "mpc_eval.hpp", "mpc_solver.hpp",
-                                                  "mpc_device.hpp", "mpc_game.hpp")]
+                                                  "mpc_device.hpp", "mpc_game.hpp", "mpc_solo.hpp")]
 _HDR = os.path.join(os.path.dirname(_HERE), "include", "mpc_hip.h")
 
 MODEL_KINEMATIC, MODEL_PACEJKA = 0, 1
@@ -25,7 +25,7 @@ EXPORTS = [
     "mpc_rhs", "mpc_rollout", "mpc_stage_errors", "mpc_stage_cost", "mpc_eval_cost_grad", "mpc_prox_step",
     "mpc_lbfgs_apply", "mpc_solve_batch", "mpc_closed_loop", "mpc_last_solve_info",
     "mpc_last_solve_info2", "mpc_math_probe", "mpc_set_groups", "mpc_last_kernel_ms", "mpc_lane_payoff",
-    "mpc_set_profile", "mpc_last_speculation",
+    "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
 ]
 
 
@@ -106,6 +106,8 @@ def load():
     L.mpc_set_profile.argtypes = [vp, ci]
     L.mpc_set_groups.argtypes = [vp, ci]
     L.mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.mpc_last_kernel_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.mpc_set_solo_max.argtypes = [vp, ci]
     for name in EXPORTS:
         if name != "mpc_last_error":
             getattr(L, name).restype = ci

@@ -2,6 +2,7 @@
 // orchestration of the batched MPC solve on one MI355X.  One process / one handle per GPU.
 #include "../../include/mpc_hip.h"
 #include "mpc_aux.hpp"
+#include "mpc_solo.hpp"
 #include "mpc_game.hpp"
 
 #include <algorithm>
@@ -34,17 +35,23 @@ struct mpc_handle {
     bool fused_eval = true;     // K1b + K1c in one launch (MPC_UNFUSED_EVAL: the two-kernel path)
     int fused_max = 16384;      // ... while a round holds at most this many requests (MPC_FUSED_MAX)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
+    int num_cus = 256;
+    int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
+                                // wave-per-agent kernel (MPC_SOLO_MAX; 0 = rounds only)
     int Bp_alloc = 0;      // workspace capacity (agents)
     char *arena = nullptr; // one device allocation carved into the Workspace arrays
     size_t arena_bytes = 0;
     Workspace ws{};
     int *host_counts = nullptr; // pinned: [2 poll windows][MPC_MAX_GROUPS][2]
     hipEvent_t pollev[2][MPC_MAX_GROUPS] = {{nullptr}};
+    hipEvent_t soloev[MPC_MAX_GROUPS][2] = {{nullptr}}; // profile mode: around a group's persistent-kernel launch
     // profiling of the last solve
     bool profile = false;
     int64_t rounds = 0, evals_grad = 0, evals_cost = 0, launches = 0;
     double eval_ms = 0.0, step_ms = 0.0, lbfgs_ms = 0.0;
-    double kernel_ms[4] = {0, 0, 0, 0}; // step, K1a rollout, K1b stage, K1c adjoint (profile mode)
+    double kernel_ms[5] = {0, 0, 0, 0, 0}; // step, K1a rollout, K1b stage, K1c adjoint, solo (profile mode)
+    int64_t kernel_launches[5] = {0, 0, 0, 0, 0};
+    int64_t solo_agents = 0;    // agents finished by the persistent kernel in the last solve
     int64_t spec_issued = 0, spec_used = 0; // speculative channel-2 gradients of the last solve
     int64_t lbfgs_rows = 0; // history pairs read by K3 (each is read twice: 4*n*8 bytes per pair)
     std::vector<hipEvent_t> ev_pool;
@@ -170,11 +177,16 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
+    if (getenv("MPC_SOLO_MAX")) h->solo_max = atoi(getenv("MPC_SOLO_MAX"));
     h->cfg = *cfg;
     int rc = make_devcfg(*cfg, h->dc);
     if (rc) { delete h; return rc; }
     h->device = device;
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_counts, 256, hipHostMallocDefault);
     if (e != hipSuccess) { delete h; return fail(MPC_E_HIP, std::string("mpc_create: ") + hipGetErrorString(e)); }
     const char *p = getenv("MPC_PROFILE");
@@ -196,6 +208,7 @@ extern "C" int mpc_destroy(mpc_handle *h)
     for (int g = 0; g < MPC_MAX_GROUPS; g++) if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
     for (int g = 0; g <= MPC_MAX_GROUPS; g++) if (h->gevent[g]) (void)hipEventDestroy(h->gevent[g]);
     for (int b = 0; b < 2; b++) for (int g = 0; g < MPC_MAX_GROUPS; g++) if (h->pollev[b][g]) (void)hipEventDestroy(h->pollev[b][g]);
+    for (int b = 0; b < 2; b++) for (int g = 0; g < MPC_MAX_GROUPS; g++) if (h->soloev[g][b]) (void)hipEventDestroy(h->soloev[g][b]);
     delete h;
     return MPC_OK;
 }
@@ -236,6 +249,7 @@ static int reserve(mpc_handle *h, int B)
     w.agent_of = ip; ip += St;
     w.counts = ip; // 8 ints per group
     w.totals = (unsigned long long *)(ip + 8 * MPC_MAX_GROUPS);
+    w.solo_ctr = (int *)(w.totals + 8); // [group][claim counter, list length]
     w.Bp = Bp; w.B = B; w.St = (int)St; w.Ls = Bp;
     w.ws_xe = w.xe; w.ws_ge = w.ge; w.ws_yhe = w.yhe; w.ws_Sig = w.Sig;
     HIPCHK(hipMemset(base, 0, bytes));
@@ -255,7 +269,7 @@ static int reserve_stage(mpc_handle *h, size_t bytes)
 static inline dim3 grid_for(int B, int block) { return dim3((unsigned)((B + block - 1) / block)); }
 
 template <int MODEL>
-static void launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
+static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
                           int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1)
 {
     const DevCfg &c = h->dc;
@@ -265,7 +279,7 @@ static void launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
     // but late in a solve dispatching thousands of them costs more than the work)
     int nblk = counts ? 2 * (w.Bp / 64) : ((nG + 63) / 64 + (nC + 63) / 64);
     if (counts && slot_bound >= 0) nblk = std::min(nblk, (slot_bound + 126) / 64 + 1);
-    if (nblk == 0) return;
+    if (nblk == 0) return true;
     const size_t lds = sizeof(double) * 64 * (size_t)(c.n + 1) + 64 * sizeof(int);
     bool wide = false;
     if constexpr (MODEL == KIN) {
@@ -289,7 +303,7 @@ static void launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         else
             hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, false>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC);
         if (evb) (void)hipEventRecord(evb, s);
-        return;
+        return true;
     }
     if (shared)
         hipLaunchKernelGGL((stage_kernel<MODEL, true>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
@@ -297,12 +311,14 @@ static void launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         hipLaunchKernelGGL((stage_kernel<MODEL, false>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
     if (evb) (void)hipEventRecord(evb, s);
     hipLaunchKernelGGL((adjoint_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), 0, s, c, w, counts, nG, nC);
+    return false;
 }
-static void launch_eval(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
+// returns true when K1b and K1c ran as one launch
+static bool launch_eval(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
                         int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1)
 {
-    if (h->dc.model == PAC) launch_eval_t<PAC>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
-    else launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
+    if (h->dc.model == PAC) return launch_eval_t<PAC>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
+    return launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
 }
 
 static int check_common(mpc_handle *h, int B, const char *who)
@@ -487,6 +503,48 @@ static void launch_step(mpc_handle *h, const Workspace &w, hipStream_t s, int *l
     } else launch_step_t<2, 0>(h, w, s, lists, counts, counts_next);
 }
 
+// The persistent wave-per-agent kernel for the agents of view `v` that are still running (`listed`:
+// a list of them is built first; otherwise every agent of the view is claimed).  `bound` = an upper
+// bound on the number of agents it will find.
+template <int MODEL, int NE, int MC>
+static void launch_solo_t(mpc_handle *h, const Workspace &v, hipStream_t s, int *ctr, bool listed, int bound,
+                          long long max_trips)
+{
+    const DevCfg &c = h->dc;
+    int *list = listed ? v.lists : nullptr;   // the round lists are free once the group leaves the rounds
+    if (listed)
+        hipLaunchKernelGGL(solo_list_kernel, dim3((unsigned)((v.B + 255) / 256)), dim3(256), 0, s, v, list, ctr);
+    const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.N, c.n, c.M, MC < 0);
+    int nblk = (bound + SOLO_WAVES - 1) / SOLO_WAVES;
+    nblk = std::max(1, std::min(nblk, 4 * h->num_cus)); // one wave per SIMD is resident (registers); the rest queues
+    hipLaunchKernelGGL((solo_kernel<MODEL, NE, MC>), dim3((unsigned)nblk), dim3(64 * SOLO_WAVES), lds, s, c, v, list,
+                       ctr, max_trips);
+}
+template <int MODEL>
+static void launch_solo_m(mpc_handle *h, const Workspace &v, hipStream_t s, int *ctr, bool listed, int bound,
+                          long long max_trips)
+{
+    const DevCfg &c = h->dc;
+    if (c.n <= 64) { // the same variant choice as launch_step: results do not depend on it
+        if (!h->step_regs && c.M * c.n <= 800) launch_solo_t<MODEL, 1, -1>(h, v, s, ctr, listed, bound, max_trips);
+        else if (c.M <= 20) launch_solo_t<MODEL, 1, 20>(h, v, s, ctr, listed, bound, max_trips);
+        else launch_solo_t<MODEL, 1, 0>(h, v, s, ctr, listed, bound, max_trips);
+    } else launch_solo_t<MODEL, 2, 0>(h, v, s, ctr, listed, bound, max_trips);
+}
+static void launch_solo(mpc_handle *h, const Workspace &v, hipStream_t s, int *ctr, bool listed, int bound,
+                        long long max_trips)
+{
+    if (h->dc.model == PAC) launch_solo_m<PAC>(h, v, s, ctr, listed, bound, max_trips);
+    else launch_solo_m<KIN>(h, v, s, ctr, listed, bound, max_trips);
+}
+static bool solo_fits(const mpc_handle *h)
+{
+    const DevCfg &c = h->dc;
+    const bool hist = c.n <= 64 && !h->step_regs && c.M * c.n <= 800;
+    const size_t per = c.model == PAC ? solo_lds_doubles<PAC>(c.N, c.n, c.M, hist) : solo_lds_doubles<KIN>(c.N, c.n, c.M, hist);
+    return c.N <= 64 && per * SOLO_WAVES * sizeof(double) <= 64 * 1024;
+}
+
 // a view of the workspace restricted to agents [lo, hi): local agent ids, own lists / scratch
 static Workspace group_view(const Workspace &w, const DevCfg &c, int g, int lo, int hi)
 {
@@ -528,19 +586,41 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     const DevCfg &c = h->dc;
     Workspace &w = h->ws;
     const int B = w.B;
-    HIPCHK(hipMemsetAsync(w.counts, 0, 8 * MPC_MAX_GROUPS * sizeof(int) + 8 * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(w.counts, 0, 8 * MPC_MAX_GROUPS * sizeof(int) + 8 * sizeof(unsigned long long) +
+                                           2 * MPC_MAX_GROUPS * sizeof(int), s));
     hipLaunchKernelGGL(init_kernel, dim3((unsigned)(((size_t)B * REC + 255) / 256)), dim3(256), 0, s, c, w);
     h->rounds = 0; h->evals_grad = 0; h->evals_cost = 0; h->eval_ms = 0.0; h->step_ms = 0.0;
-    h->lbfgs_ms = 0.0; h->lbfgs_rows = 0;
+    h->lbfgs_ms = 0.0; h->lbfgs_rows = 0; h->solo_agents = 0;
+    for (int k = 0; k < 5; k++) { h->kernel_ms[k] = 0.0; h->kernel_launches[k] = 0; }
+    // an agent waits for at most ~(4 + 11 * 60) evaluations per inner iteration in the worst case;
+    // this bound only guards against a runaway loop
+    const long long max_rounds = 64LL * ((long long)c.max_total_inner + 16) + 1024;
+    const bool solo_ok = h->solo_max > 0 && solo_fits(h);
+    size_t nev = 0;               // events 0 .. nev-1 of the pool: five per sampled launch set
+    bool solo_timed[MPC_MAX_GROUPS] = {false};
+    auto solo_events = [&](int g, hipStream_t st, int which) { // profile mode: (start, stop) around the launch
+        if (!h->profile) return;
+        if (!h->soloev[g][which] && hipEventCreate(&h->soloev[g][which]) != hipSuccess) { h->soloev[g][which] = nullptr; return; }
+        (void)hipEventRecord(h->soloev[g][which], st);
+        if (which == 1 && h->soloev[g][0]) solo_timed[g] = true;
+    };
+    long long launch_sets = 0, unfused_sets = 0, solo_launches = 0;
+    long long rounds_done[MPC_MAX_GROUPS] = {0};
+    int ng = 0;
+    bool all_solo = false;
+    if (solo_ok && B <= h->solo_max) {
+        // small batch: every agent is solved by one wave of the persistent kernel from the start
+        all_solo = true;
+    }
+    Workspace gv[MPC_MAX_GROUPS];
+    hipStream_t gs[MPC_MAX_GROUPS];
     // groups: contiguous agent ranges (multiples of 64), each with its own stream; measured at
     // B = 65536: 1 group 0.258 s, 2 groups 0.224 s, 3 groups 0.220 s per solve
     int G = h->ngroups > 0 ? h->ngroups : (B >= 24576 ? 3 : B >= 16384 ? 2 : 1);
     if (G > MPC_MAX_GROUPS) G = MPC_MAX_GROUPS;
     while (G > 1 && B / G < 1024) G--;
+    if (all_solo) G = 1;
     const int per = (((B + G - 1) / G) + 63) & ~63;
-    Workspace gv[MPC_MAX_GROUPS];
-    hipStream_t gs[MPC_MAX_GROUPS];
-    int ng = 0;
     for (int g = 0; g < G; g++) {
         const int lo = g * per, hi = std::min(B, lo + per);
         if (lo >= hi) break;
@@ -558,13 +638,9 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             HIPCHK(hipStreamWaitEvent(gs[g], h->gevent[MPC_MAX_GROUPS], 0));
         }
     }
-    // an agent waits for at most ~(4 + 11 * 60) evaluations per inner iteration in the worst case;
-    // this bound only guards against a runaway loop
-    const long long max_rounds = 64LL * ((long long)c.max_total_inner + 16) + 1024;
     static const int check_env = getenv("MPC_CHECK_EVERY") ? atoi(getenv("MPC_CHECK_EVERY")) : 0;
     const int check_every = check_env > 0 ? check_env : 8;
-    size_t nev = 0;
-    long long round = 0, rounds_done[MPC_MAX_GROUPS] = {0}, launch_sets = 0;
+    long long round = 0;
     bool active[MPC_MAX_GROUPS];
     // upper bound on a group's requests per round: at most two per running agent (evaluation +
     // speculative gradient); every running agent has at least one request in a round and agents only
@@ -572,6 +648,13 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     int slot_bound[MPC_MAX_GROUPS];
     for (int g = 0; g < ng; g++) { active[g] = true; slot_bound[g] = 2 * gv[g].B; }
     int nactive = ng;
+    if (all_solo) {
+        solo_events(0, gs[0], 0);
+        launch_solo(h, gv[0], gs[0], w.solo_ctr, false, B, max_rounds);
+        solo_events(0, gs[0], 1);
+        solo_launches++;
+        active[0] = false; nactive = 0;
+    }
     long long window = 0;
     bool polled[2][MPC_MAX_GROUPS] = {{false}};
     while (nactive > 0) {
@@ -591,10 +674,11 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             if (ev[0]) (void)hipEventRecord(ev[0], gs[g]);
             launch_step(h, v, gs[g], lists, counts, counts_next);
             if (ev[1]) (void)hipEventRecord(ev[1], gs[g]);
-            launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], slot_bound[g]);
+            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], slot_bound[g]);
             if (ev[4]) (void)hipEventRecord(ev[4], gs[g]);
             rounds_done[g]++;
             launch_sets++;
+            unfused_sets += !fused;
         }
         round++;
         if (round % check_every == 0 || round >= max_rounds) {
@@ -619,9 +703,18 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
                     if (!polled[pb][g] || !active[g]) continue;
                     HIPCHK(hipEventSynchronize(h->pollev[pb][g]));
                     const int reqs = h->host_counts[16 * pb + 2 * g] + h->host_counts[16 * pb + 2 * g + 1];
-                    if (reqs == 0) { active[g] = false; nactive--; }
-                    slot_bound[g] = std::min(slot_bound[g], 2 * reqs);
                     polled[pb][g] = false;
+                    if (reqs == 0) { active[g] = false; nactive--; continue; }
+                    slot_bound[g] = std::min(slot_bound[g], 2 * reqs);
+                    if (solo_ok && reqs <= h->solo_max) {
+                        // few agents left in this group: they finish in the persistent kernel, each in
+                        // its own wave, instead of waiting for four launches per evaluation
+                        solo_events(g, gs[g], 0);
+                        launch_solo(h, gv[g], gs[g], w.solo_ctr + 2 * g, true, reqs, max_rounds);
+                        solo_events(g, gs[g], 1);
+                        solo_launches++;
+                        active[g] = false; nactive--;
+                    }
                 }
             }
             window++;
@@ -637,15 +730,18 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     for (int g = 0; g < ng; g++) h->rounds = std::max<int64_t>(h->rounds, rounds_done[g]);
     {
         unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int sctr[2 * MPC_MAX_GROUPS];
         hipLaunchKernelGGL(totals_kernel, grid_for(B, 256), dim3(256), 0, s, w);
         HIPCHK(hipMemcpyAsync(tot, w.totals, sizeof tot, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sctr, w.solo_ctr, sizeof sctr, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->evals_grad = (int64_t)tot[0]; h->evals_cost = (int64_t)tot[1]; h->lbfgs_rows = (int64_t)tot[2];
         h->spec_issued = (int64_t)tot[4]; h->spec_used = (int64_t)tot[5];
+        if (all_solo) h->solo_agents = B;
+        else for (int g = 0; g < ng; g++) h->solo_agents += sctr[2 * g + 1];
     }
     if (h->profile) {
         HIPCHK(hipStreamSynchronize(s));
-        for (int k = 0; k < 4; k++) h->kernel_ms[k] = 0.0;
         for (size_t i = 0; i + 4 < nev; i += 5) {
             for (int k = 0; k < 4; k++) {
                 float d = 0.f;
@@ -657,10 +753,18 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         const double sampled = (double)(nev / 5);
         const double scale = sampled > 0 ? (double)launch_sets / sampled : 0.0;
         for (int k = 0; k < 4; k++) h->kernel_ms[k] *= scale;
+        for (int g = 0; g < MPC_MAX_GROUPS; g++) {
+            float d = 0.f;
+            if (solo_timed[g]) (void)hipEventElapsedTime(&d, h->soloev[g][0], h->soloev[g][1]);
+            h->kernel_ms[4] += d;
+        }
         h->step_ms = h->kernel_ms[0];
         h->eval_ms = h->kernel_ms[1] + h->kernel_ms[2] + h->kernel_ms[3];
     }
     h->launches = (int64_t)launch_sets;
+    h->kernel_launches[0] = h->kernel_launches[1] = h->kernel_launches[2] = launch_sets;
+    h->kernel_launches[3] = unfused_sets;
+    h->kernel_launches[4] = solo_launches;
     HIPCHK(hipGetLastError());
     return MPC_OK;
 }
@@ -747,6 +851,24 @@ extern "C" int mpc_last_kernel_ms(mpc_handle *h, double *out4)
 {
     if (!h || !out4) return fail(MPC_E_ARG, "mpc_last_kernel_ms: null argument");
     for (int k = 0; k < 4; k++) out4[k] = h->kernel_ms[k];
+    return MPC_OK;
+}
+
+extern "C" int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int64_t *solo_agents)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_last_kernel_profile: null handle");
+    for (int k = 0; k < 5; k++) {
+        if (ms5) ms5[k] = h->kernel_ms[k];
+        if (launches5) launches5[k] = h->kernel_launches[k];
+    }
+    if (solo_agents) *solo_agents = h->solo_agents;
+    return MPC_OK;
+}
+
+extern "C" int mpc_set_solo_max(mpc_handle *h, int max_requests)
+{
+    if (!h || max_requests < 0) return fail(MPC_E_ARG, "mpc_set_solo_max: bad argument");
+    h->solo_max = max_requests;
     return MPC_OK;
 }
 

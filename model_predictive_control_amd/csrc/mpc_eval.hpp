@@ -99,39 +99,21 @@ rollout_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
 // summed in order (phase C).  Same helper functions with fixed roundings as the thread-per-agent
 // kernel, so a request gets the same bits whichever kernel serves it.  Kinematic model, nfe = 4,
 // N <= 64 (up to four passes of 64 RK4 steps).
-__global__ void __launch_bounds__(256)
-rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
-                    const int *__restrict__ counts)
+// The body of the wave-per-request rollout, shared by rollout_wide_kernel (states to the slot-indexed
+// scratch) and the persistent solo kernel (states to the wave's LDS): `put(k, i, v)` stores component
+// i of the state at the end of stage k - 1 (k = 0: the initial state).  d / dl are the inputs of
+// stage `lane` (lanes >= N: zeros); `row` is the control row (fallback path only).
+template <class Put>
+__device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double *__restrict__ row,
+                                                 const double (&x0)[4], double d, double dl, int lane, Put put)
 {
-    const SlotMap sm(counts, 0, 0);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int uslot = blockIdx.x * 4 + wv;
-    if (uslot >= sm.nblk * 64) return;
-    const bool is_g = uslot < sm.gpad;
-    const int kslot = is_g ? uslot : uslot - sm.gpad;
-    const bool active = kslot < (is_g ? sm.nG : sm.nC);
-    const int raw = active ? (is_g ? lists : lists + w.Ls)[kslot] : -1;
-    if (lane == 0) w.agent_of[uslot] = raw;
-    if (!active) return;
-    const int a = raw & AGENT_MASK;
-    const int N = c.N, n = c.n;
-    const size_t St = (size_t)w.St;
-    const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)a * n;
-    // lane k < N owns stage k: its inputs, and later the state at the end of the stage
+    const int N = c.N;
     const bool stage_lane = lane < N;
-    const double d = stage_lane ? row[2 * lane] : 0.0, dl = stage_lane ? row[2 * lane + 1] : 0.0;
-    if (stage_lane) {
-        w.useq[(size_t)(2 * lane) * St + uslot] = d;
-        w.useq[(size_t)(2 * lane + 1) * St + uslot] = dl;
-    }
     StageInput<KIN> u;
     prep_input(c, d, dl, u);
-    double x0[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) x0[i] = w.x0[(size_t)a * 4 + i];
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) w.trajx[(size_t)i * St + uslot] = x0[i];
+        for (int i = 0; i < 4; i++) put(0, i, x0[i]);
     }
     // ---- phase A: heading and speed along the horizon (uniform, serial); lane s & 63 keeps the
     // (heading, speed) at the start of RK4 step s, lane k the state at the end of stage k
@@ -166,7 +148,7 @@ rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
                 prep_input(c, row[2 * k], row[2 * k + 1], uk);
                 stage_forward<KIN>(c, uk, x);
 #pragma unroll
-                for (int i = 0; i < 4; i++) w.trajx[(size_t)((k + 1) * 4 + i) * St + uslot] = x[i];
+                for (int i = 0; i < 4; i++) put(k + 1, i, x[i]);
             }
         }
         return;
@@ -199,10 +181,40 @@ rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
             if (lane == k) { epx = px; epy = py; }
         }
     }
+    if (stage_lane) { put(lane + 1, 0, epx); put(lane + 1, 1, epy); put(lane + 1, 2, eph); put(lane + 1, 3, ev); }
+}
+
+__global__ void __launch_bounds__(256)
+rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
+                    const int *__restrict__ counts)
+{
+    const SlotMap sm(counts, 0, 0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int uslot = blockIdx.x * 4 + wv;
+    if (uslot >= sm.nblk * 64) return;
+    const bool is_g = uslot < sm.gpad;
+    const int kslot = is_g ? uslot : uslot - sm.gpad;
+    const bool active = kslot < (is_g ? sm.nG : sm.nC);
+    const int raw = active ? (is_g ? lists : lists + w.Ls)[kslot] : -1;
+    if (lane == 0) w.agent_of[uslot] = raw;
+    if (!active) return;
+    const int a = raw & AGENT_MASK;
+    const int N = c.N, n = c.n;
+    const size_t St = (size_t)w.St;
+    const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)a * n;
+    // lane k < N owns stage k: its inputs, and later the state at the end of the stage
+    const bool stage_lane = lane < N;
+    const double d = stage_lane ? row[2 * lane] : 0.0, dl = stage_lane ? row[2 * lane + 1] : 0.0;
     if (stage_lane) {
-        double *t = w.trajx + (size_t)((lane + 1) * 4) * St + uslot;
-        t[0] = epx; t[St] = epy; t[2 * St] = eph; t[3 * St] = ev;
+        w.useq[(size_t)(2 * lane) * St + uslot] = d;
+        w.useq[(size_t)(2 * lane + 1) * St + uslot] = dl;
     }
+    double x0[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x0[i] = w.x0[(size_t)a * 4 + i];
+    double *const tj = w.trajx + uslot;
+    kin_wide_rollout(c, row, x0, d, dl, lane,
+                     [=](int k, int i, double v) { tj[(size_t)(k * 4 + i) * St] = v; });
 }
 
 // per (slot, stage) record written for gradient requests: dL/dx (NX), dL/du (2), T (NX x NX)
@@ -337,91 +349,73 @@ adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts
 // SPB consecutive slots per stage from the slot-indexed scratch.
 template <int MODEL> struct FusedBlk { static constexpr int BLK = MODEL == PAC ? 128 : 256; };
 
-template <int MODEL, bool SHARED_CL>
-__global__ void __launch_bounds__(FusedBlk<MODEL>::BLK, 2)
-stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm)
+// K1b for one (request, stage): nearest point, stage cost, ALM terms and -- for gradient requests --
+// the stage's cost gradient and transition sensitivities, left as a record in LDS: field f of the
+// record at r[f * NS] (fields: dL/dx (NX), dL/du (2), T (NX x NX); field JS = the stage cost).  Shared
+// by stage_adjoint_kernel and the persistent solo kernel.
+template <int MODEL>
+__device__ __forceinline__ void stage_record_lds(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
+                                                 int k, const double (&xs)[ModelDim<MODEL>::NX],
+                                                 const double (&xe)[ModelDim<MODEL>::NX], double d, double dl,
+                                                 const double *__restrict__ clp, double *r, int NS)
 {
-    constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE, BLK = FusedBlk<MODEL>::BLK;
-    extern __shared__ double s_rec[];                    // [JS + 1][N][SPB]; row JS = stage cost
-    const SlotMap sm(counts, nG_imm, nC_imm);
-    const int N = c.N, n = c.n, SPB = BLK / N;
-    const int slot0 = blockIdx.x * SPB, nslots = sm.nblk * 64;
-    if (slot0 >= nslots) return;
-    const size_t St = (size_t)w.St;
-    const int NS = N * SPB;
-    {
-        const int k = threadIdx.x / SPB, j = threadIdx.x - k * SPB;
-        const int uslot = slot0 + j;
-        const int raw = (k < N && uslot < nslots) ? w.agent_of[uslot] : -1;
-        if (raw >= 0) {
-            const bool is_g = uslot < sm.gpad;
-            const int a = raw & AGENT_MASK;
-            const bool ch2 = (raw & CH2_BIT) != 0;   // speculative channel: only the gradient is kept
-            double xs[NX], xe[NX];
+    constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
+    const int idx = nearest_index(c, clp, xe[0], xe[1]);
+    Geom g;
+    load_geom(c, clp, idx, g);
+    double xb[NX], ub[2] = {0.0, 0.0};
 #pragma unroll
-            for (int i = 0; i < NX; i++) {
-                xs[i] = w.trajx[(size_t)(k * NX + i) * St + uslot];
-                xe[i] = w.trajx[(size_t)((k + 1) * NX + i) * St + uslot];
-            }
-            const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
-            const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
-            const int idx = nearest_index(c, clp, xe[0], xe[1]);
-            Geom g;
-            load_geom(c, clp, idx, g);
-            double xb[NX], ub[2] = {0.0, 0.0};
+    for (int i = 0; i < NX; i++) xb[i] = 0.0;
+    double L = is_g ? stage_cost<MODEL, true>(c, g, xe, d, dl, xb, ub)
+                    : stage_cost<MODEL, false>(c, g, xe, d, dl, xb, ub);
+    if (c.sm) {
+        const size_t am = (size_t)a * c.m;
 #pragma unroll
-            for (int i = 0; i < NX; i++) xb[i] = 0.0;
-            double L = is_g ? stage_cost<MODEL, true>(c, g, xe, d, dl, xb, ub)
-                            : stage_cost<MODEL, false>(c, g, xe, d, dl, xb, ub);
-            if (c.sm) {
-                const size_t am = (size_t)a * c.m;
-#pragma unroll
-                for (int i = 0; i < NX; i++) {
-                    if (i < c.sm) {
-                        const size_t kk = am + (size_t)(k * c.sm + i);
-                        const double gv = stage_constraint<MODEL>(c, g, xe, i);
-                        double lb, ubd;
-                        constraint_bounds(c, i, lb, ubd);
-                        const double sg = w.Sig[kk];
-                        const double zeta = gv + w.y[kk] / sg;
-                        const double zhat = fmax(lb, fmin(zeta, ubd));
-                        const double dd = zeta - zhat;
-                        const double yh = sg * dd;
-                        L += 0.5 * dd * yh;
-                        if (!ch2) w.yhe[kk] = yh;
-                        if (is_g) stage_constraint_adjoint<MODEL>(c, g, xe, i, yh, xb);
-                    }
-                }
-            }
-            double *r = s_rec + k * SPB + j;
-            r[(size_t)JS * NS] = L;
-            if (is_g) {
-                StageInput<MODEL> u;
-                prep_input(c, d, dl, u);
-                double T[NX][NX];
-                stage_tangents<MODEL>(c, u, xs, T);
-#pragma unroll
-                for (int i = 0; i < NX; i++) r[(size_t)i * NS] = xb[i];
-                r[(size_t)NX * NS] = ub[0];
-                r[(size_t)(NX + 1) * NS] = ub[1];
-#pragma unroll
-                for (int dd = 0; dd < NX; dd++) {
-#pragma unroll
-                    for (int i = 0; i < NX; i++) r[(size_t)(NX + 2 + dd * NX + i) * NS] = T[dd][i];
-                }
+        for (int i = 0; i < NX; i++) {
+            if (i < c.sm) {
+                const size_t kk = am + (size_t)(k * c.sm + i);
+                const double gv = stage_constraint<MODEL>(c, g, xe, i);
+                double lb, ubd;
+                constraint_bounds(c, i, lb, ubd);
+                const double sg = w.Sig[kk];
+                const double zeta = gv + w.y[kk] / sg;
+                const double zhat = fmax(lb, fmin(zeta, ubd));
+                const double dd = zeta - zhat;
+                const double yh = sg * dd;
+                L += 0.5 * dd * yh;
+                if (!ch2) w.yhe[kk] = yh;
+                if (is_g) stage_constraint_adjoint<MODEL>(c, g, xe, i, yh, xb);
             }
         }
     }
-    __syncthreads();
-    if ((int)threadIdx.x >= SPB) return;
-    const int j = threadIdx.x, uslot = slot0 + j;
-    const int raw = uslot < nslots ? w.agent_of[uslot] : -1;
-    if (raw < 0) return;
-    const bool is_g = uslot < sm.gpad;
-    const int a = raw & AGENT_MASK;
-    const bool ch2 = (raw & CH2_BIT) != 0;
+    r[(size_t)JS * NS] = L;
+    if (is_g) {
+        StageInput<MODEL> u;
+        prep_input(c, d, dl, u);
+        double T[NX][NX];
+        stage_tangents<MODEL>(c, u, xs, T);
+#pragma unroll
+        for (int i = 0; i < NX; i++) r[(size_t)i * NS] = xb[i];
+        r[(size_t)NX * NS] = ub[0];
+        r[(size_t)(NX + 1) * NS] = ub[1];
+#pragma unroll
+        for (int dd = 0; dd < NX; dd++) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) r[(size_t)(NX + 2 + dd * NX + i) * NS] = T[dd][i];
+        }
+    }
+}
+
+// K1c for one request out of the LDS records: psi = sum of stage costs (stage order, as main.py:36-40)
+// and the adjoint recursion; `rec` points at the request's stage-0 record, stage k at rec + k * SK.
+template <int MODEL>
+__device__ __forceinline__ void adjoint_from_lds(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
+                                                 const double *rec, int SK, int NS)
+{
+    constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE;
+    const int N = c.N, n = c.n;
     double psi = 0.0;
-    for (int k = 0; k < N; k++) psi += s_rec[(size_t)JS * NS + k * SPB + j]; // stage order, as main.py:36-40
+    for (int k = 0; k < N; k++) psi += rec[(size_t)JS * NS + k * SK];
     if (w.psi_direct) w.psi_direct[a] = psi;
     else if (!ch2) w.rec[(size_t)a * REC + R_PSIE] = psi;
     if (!is_g) return;
@@ -430,7 +424,7 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
     for (int i = 0; i < NX; i++) lam[i] = 0.0;
     double *grow = (ch2 ? w.ge2 : w.ge) + (size_t)a * n;
     for (int k = N - 1; k >= 0; k--) {
-        const double *jr = s_rec + k * SPB + j;
+        const double *jr = rec + k * SK;
 #pragma unroll
         for (int i = 0; i < NX; i++) lam[i] += jr[(size_t)i * NS];
         double gu[2], lz[NZ];
@@ -453,6 +447,45 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
         grow[2 * k] = gu[0];
         grow[2 * k + 1] = gu[1];
     }
+}
+
+template <int MODEL, bool SHARED_CL>
+__global__ void __launch_bounds__(FusedBlk<MODEL>::BLK, 2)
+stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm)
+{
+    constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE, BLK = FusedBlk<MODEL>::BLK;
+    extern __shared__ double s_rec[];                    // [JS + 1][N][SPB]; row JS = stage cost
+    const SlotMap sm(counts, nG_imm, nC_imm);
+    const int N = c.N, SPB = BLK / N;
+    const int slot0 = blockIdx.x * SPB, nslots = sm.nblk * 64;
+    if (slot0 >= nslots) return;
+    const size_t St = (size_t)w.St;
+    const int NS = N * SPB;
+    {
+        const int k = threadIdx.x / SPB, j = threadIdx.x - k * SPB;
+        const int uslot = slot0 + j;
+        const int raw = (k < N && uslot < nslots) ? w.agent_of[uslot] : -1;
+        if (raw >= 0) {
+            const bool is_g = uslot < sm.gpad;
+            const int a = raw & AGENT_MASK;
+            const bool ch2 = (raw & CH2_BIT) != 0;   // speculative channel: only the gradient is kept
+            double xs[NX], xe[NX];
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                xs[i] = w.trajx[(size_t)(k * NX + i) * St + uslot];
+                xe[i] = w.trajx[(size_t)((k + 1) * NX + i) * St + uslot];
+            }
+            const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
+            const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
+            stage_record_lds<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, s_rec + k * SPB + j, NS);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= SPB) return;
+    const int j = threadIdx.x, uslot = slot0 + j;
+    const int raw = uslot < nslots ? w.agent_of[uslot] : -1;
+    if (raw < 0) return;
+    adjoint_from_lds<MODEL>(c, w, raw & AGENT_MASK, (raw & CH2_BIT) != 0, uslot < sm.gpad, s_rec + j, SPB, NS);
 }
 
 } // namespace mpc

@@ -1,0 +1,120 @@
+// mpc_solo.hpp -- the whole solve of an agent inside ONE wavefront, without returning to the host.
+//
+// A round of the batched path (step_kernel -> K1a -> K1b -> K1c) costs four dependent launches
+// whatever the number of agents in it; once few agents are left that is pure latency (a tail round
+// with a handful of requests still takes ~55 us), and the slowest agent of a batch needs hundreds of
+// rounds more than the average one.  The persistent kernel below takes over when a sub-batch group has
+// few running agents left (and serves small batches from the start): a wave claims a running agent,
+// then loops  advance_agent -> evaluation -> advance_agent ...  until the agent is done, and claims
+// the next one.  Nothing is exchanged between waves, so no grid-wide synchronisation is needed and
+// every wave reaches its exit (the claim counter runs out; an agent's state machine is bounded by the
+// solver's own iteration budgets, and a trip limit guards the loop besides).
+//
+// The evaluation inside the wave reuses the device functions of the round path with the same
+// roundings -- the wave-per-request rollout (kin_wide_rollout) for the kinematic model, the
+// thread-per-agent stage_forward on one lane otherwise; stage k of the horizon on lane k
+// (stage_record_lds); the adjoint recursion on one lane (adjoint_from_lds) -- so an agent gets the
+// same bits whichever path serves it, and the host may switch on the live request counts.
+// Speculative gradients are not issued here (two evaluations of one agent run one after the other in
+// its wave, so a speculation can only lose); one that is pending when the agent arrives is consumed.
+#pragma once
+#include "mpc_eval.hpp"
+
+namespace mpc {
+
+constexpr int SOLO_WAVES = 1; // one wave per workgroup: nothing is shared between waves, and the dispatcher places them freely
+
+// doubles of LDS one wave needs: history copy (MC < 0), trajectory, stage records
+template <int MODEL> __host__ __device__ inline size_t solo_lds_doubles(int N, int n, int M, bool hist)
+{
+    constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
+    return (hist ? (size_t)2 * M * n : 0) + (size_t)(N + 1) * NX + (size_t)(JS + 1) * N;
+}
+
+// one evaluation (cost, or cost + gradient) of agent a's row `xrow` by the whole wave
+template <int MODEL>
+__device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, int a, int lane, bool ch2,
+                                          bool is_g, double *traj, double *rec)
+{
+    constexpr int NX = ModelDim<MODEL>::NX;
+    const int N = c.N, n = c.n;
+    const double *__restrict__ row = (ch2 ? w.xe2 : w.xe) + (size_t)a * n;
+    const bool stage_lane = lane < N;
+    const double d = stage_lane ? row[2 * lane] : 0.0, dl = stage_lane ? row[2 * lane + 1] : 0.0;
+    double x0[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) x0[i] = w.x0[(size_t)a * NX + i];
+    bool wide = false;
+    if constexpr (MODEL == KIN) {
+        if (c.nfe == 4) {                                  // uniform
+            wide = true;
+            kin_wide_rollout(c, row, x0, d, dl, lane, [=](int k, int i, double v) { traj[k * 4 + i] = v; });
+        }
+    }
+    if (!wide && lane == 0) {                              // the serial recurrence, as rollout_kernel runs it
+        double x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) { x[i] = x0[i]; traj[i] = x0[i]; }
+        for (int k = 0; k < N; k++) {
+            StageInput<MODEL> u;
+            prep_input(c, row[2 * k], row[2 * k + 1], u);
+            stage_forward<MODEL>(c, u, x);
+#pragma unroll
+            for (int i = 0; i < NX; i++) traj[(k + 1) * NX + i] = x[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                       // LDS is in order within a wave
+    if (stage_lane) {
+        double xs[NX], xe[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) { xs[i] = traj[lane * NX + i]; xe[i] = traj[(lane + 1) * NX + i]; }
+        const double *__restrict__ clp = w.cl_index ? w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S : w.cl;
+        stage_record_lds<MODEL>(c, w, a, ch2, is_g, lane, xs, xe, d, dl, clp, rec + lane, N);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) adjoint_from_lds<MODEL>(c, w, a, ch2, is_g, rec, 1, N);
+}
+
+// list of the agents of this view that are still running (phase != PH_DONE), in agent order inside a
+// workgroup; also resets the claim counter's companion (the number of entries)
+__global__ void __launch_bounds__(256) solo_list_kernel(const Workspace w, int *__restrict__ list, int *__restrict__ ctr)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = a < w.B && w.rec[(size_t)a * REC + R_PHASE] != 0.0;
+    const unsigned long long bal = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && bal != 0ull) base = atomicAdd(&ctr[1], __popcll(bal));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (on) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = a;
+}
+
+// ctr[0] = claim counter, ctr[1] = number of list entries (list == nullptr: every agent of the view)
+template <int MODEL, int NE, int MC>
+__global__ void __launch_bounds__(64 * SOLO_WAVES, 1)
+solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int *__restrict__ ctr,
+            long long max_trips)
+{
+    extern __shared__ double s_solo[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t per_wave = solo_lds_doubles<MODEL>(c.N, c.n, c.M, MC < 0);
+    double *hist = s_solo + (size_t)wv * per_wave;
+    double *traj = hist + (MC < 0 ? (size_t)2 * c.M * c.n : 0);
+    double *rec = traj + (size_t)(c.N + 1) * ModelDim<MODEL>::NX;
+    const int total = list ? ctr[1] : w.B;
+    for (;;) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&ctr[0], 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= total) break;
+        const int a = list ? list[i] : i;
+        for (long long trip = 0; trip < max_trips; trip++) {
+            const AgentIn<NE> in = load_agent<NE>(c, w, a, lane);
+            const int req = advance_agent<NE, MC>(c, w, a, lane, in, hist, false, /*allow_spec=*/false);
+            if ((req & (REQ_GRAD | REQ_COST)) == 0) break;              // uniform: the agent is done
+            solo_eval<MODEL>(c, w, a, lane, false, (req & REQ_GRAD) != 0, traj, rec);
+        }
+    }
+}
+
+} // namespace mpc

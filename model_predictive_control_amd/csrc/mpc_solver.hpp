@@ -50,6 +50,7 @@ struct Workspace {
     int *lists;                                    // [2 buffers][2 kinds][Bp] agent ids
     int *counts;                                   // [2 buffers][4]
     unsigned long long *totals;                    // [8] gradient evals, cost evals, history pairs read, harness, spec issued/used
+    int *solo_ctr;                                 // [groups][2] persistent kernel: claim counter, list length
     // K1 scratch, slot-indexed SoA with stride Bp + 64 (see mpc_eval.hpp)
     double *trajx;                                 // [(N+1)*nx][St] x_0 .. x_N
     double *useq;                                  // [2N][St]       control sequence
@@ -422,7 +423,7 @@ __device__ __forceinline__ AgentIn<NE> load_agent(const DevCfg &c, const Workspa
 
 template <int NE, int MC>
 __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lane, const AgentIn<NE> &in,
-                             double *hist, bool hist_ready)
+                             double *hist, bool hist_ready, bool allow_spec = true)
 {
     const int n = c.n, m = c.m;
     const size_t an = (size_t)a * n, am = (size_t)a * m;
@@ -500,7 +501,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     // second channel, assuming x+ is accepted with step gm.  Same formulas as PH_AFTER_DL on the same
     // inputs, so the point -- and the gradient -- are bit-identical when the assumption holds.
     auto speculate = [&](double gm) {
-        if (c.no_spec) { spec = 0; return; }
+        if (c.no_spec || !allow_spec) { spec = 0; return; }
         Row<NE> qv;
         double cntJ = 0.0, xx = 0.0;
 #pragma unroll

@@ -235,6 +235,10 @@ class BatchedMPC:
         """Sub-batch pipelining over HIP streams (0 = automatic)."""
         _lib.check(self.lib.mpc_set_groups(self._h, int(groups)))
 
+    def set_solo_max(self, max_requests):
+        """Requests per round up to which a group finishes in the persistent wave-per-agent kernel (0 = off)."""
+        _lib.check(self.lib.mpc_set_solo_max(self._h, int(max_requests)))
+
     def set_profile(self, on=True):
         _lib.check(self.lib.mpc_set_profile(self._h, int(bool(on))))
 
@@ -247,9 +251,13 @@ class BatchedMPC:
         _lib.check(self.lib.mpc_last_solve_info2(self._h, C.byref(lm), C.byref(lr)))
         si, su = C.c_int64(), C.c_int64()
         _lib.check(self.lib.mpc_last_speculation(self._h, C.byref(si), C.byref(su)))
-        km = (C.c_double * 4)()
-        _lib.check(self.lib.mpc_last_kernel_ms(self._h, km))
-        return {"kernel_ms": {"step": km[0], "rollout": km[1], "stage": km[2], "adjoint": km[3]},
+        km = (C.c_double * 5)()
+        kl = (C.c_int64 * 5)()
+        sa = C.c_int64()
+        _lib.check(self.lib.mpc_last_kernel_profile(self._h, km, kl, C.byref(sa)))
+        names = ("step", "rollout", "stage", "adjoint", "solo")
+        return {"kernel_ms": {k: km[i] for i, k in enumerate(names)},
+                "launches": {k: int(kl[i]) for i, k in enumerate(names)}, "solo_agents": int(sa.value),
                 "rounds": r.value, "evals_grad": g.value, "evals_cost": c.value,
                 "eval_ms": e.value, "step_ms": s.value, "launch_pairs": int(lm.value), "lbfgs_rows": lr.value,
                 "spec_issued": si.value, "spec_used": su.value}

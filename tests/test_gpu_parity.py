@@ -373,6 +373,7 @@ def test_step_kernel_variants_are_bit_identical(dev, monkeypatch):
     """The step kernel keeps an agent's L-BFGS history either in LDS (LDS-DMA, default while
     M n <= 800) or in registers (MPC_STEP_REGS / larger n): same arithmetic, same order, so the
     two give the same bits; N = 32 (n = 64) takes the register variant by itself."""
+    monkeypatch.setenv("MPC_SOLO_MAX", "0")      # the round path (the persistent kernel has its own test)
     B, N = 300, 20
     X0 = T(synthetic_states(0, B, seed=5), dev)
     cl = T(straight_centerline(), dev)
@@ -401,6 +402,7 @@ def test_wide_rollout_is_bit_identical(dev, monkeypatch, N):
     few requests (small batches, late rounds) -- one wave per request (rollout_wide_kernel).  They
     share their arithmetic with fixed roundings, so a solve gives the same bits whichever serves it;
     agents outside the fast ranges (huge speed) take the fallback of both."""
+    monkeypatch.setenv("MPC_SOLO_MAX", "0")      # the round path (the persistent kernel has its own test)
     B = 200
     x0 = synthetic_states(0, B, seed=11)
     x0[::17, 3] = 60.0                                    # out of range for the rotation path
@@ -426,6 +428,44 @@ def test_wide_rollout_is_bit_identical(dev, monkeypatch, N):
     monkeypatch.delenv("MPC_APB")
     assert torch.equal(Uw, Ua) and torch.equal(stw, sta)
     assert (stw[:, 0] == 1).float().mean() >= (0.8 if N == 20 else 0.4)   # 300 iterations are short for N = 40
+
+
+@pytest.mark.parametrize("model,N,B,kw", [
+    (0, 20, 700, {}), (1, 12, 300, {}), (0, 40, 150, {}), (0, 32, 100, dict(lbfgs_memory=25)),
+    (1, 10, 96, dict(constr_mode=1, D_lb=[-np.inf] * 6, D_ub=[0.0] * 6, g_off=[20, 1, 1, 0.5, 1, 0.1], Sigma0=10.0)),
+    (0, 12, 200, dict(constr_mode=2, lane_halfwidth=0.05))])
+def test_persistent_kernel_is_bit_identical(dev, model, N, B, kw):
+    """The persistent wave-per-agent kernel (mpc_solo.hpp: a wave solves an agent start to finish
+    without returning to the host) against the round path, and a switch from rounds to it in
+    mid-solve: same controls, multipliers and statistics, bit for bit -- it runs the same device
+    functions.  Covers every step-kernel variant (history in LDS / registers / HBM, two elements per
+    lane), both models, per-agent centerline rows and the ALM path."""
+    from model_predictive_control_amd import bezier_curves as bc
+    x0 = synthetic_states(model, B, seed=17)
+    if kw.get("constr_mode") == 1:
+        x0[:, 0] *= 3.9 / 5.0; x0[:, 3] = np.minimum(x0[:, 3], 0.65)
+    if model == 0:
+        x0[::23, 3] = 60.0                                # outside the fast ranges of the wide rollout
+    tab = np.concatenate([straight_centerline()[None], bc.lane_change_centerlines(S=100)[:3]], 0)
+    ci = (np.arange(B) % 4).astype(np.int32)
+    X0, cl, CI = T(x0, dev), T(tab, dev), T(ci, dev, torch.int32)
+    U0 = T(np.tile([1., 0.], (B, N)), dev)
+    cfg = mp.default_config(model, N, max_total_inner=400, **kw)
+    out = []
+    for solo_max in (0, 100000, 64):          # rounds only / persistent kernel from the start / switch in mid-solve
+        eng = mp.BatchedMPC(cfg, dev)
+        eng.set_solo_max(solo_max)
+        U, lam, st = eng.solve(X0, cl, U0, cl_index=CI)
+        info = eng.last_solve_info()
+        out.append((U, lam, st, info))
+    (Ur, lr, sr, ir), (Us, ls, ss, is_), (Um, lm, sm, im) = out
+    assert ir["solo_agents"] == 0 and ir["rounds"] > 0
+    assert is_["solo_agents"] == B and is_["rounds"] == 0
+    assert 0 < im["solo_agents"] < B and im["rounds"] > 0
+    for U, lam, st in ((Us, ls, ss), (Um, lm, sm)):
+        assert torch.equal(U, Ur) and torch.equal(st, sr)
+        assert (lam is None and lr is None) or torch.equal(lam, lr)
+    assert (sr[:, 0] == 1).float().mean() >= 0.5 and torch.isfinite(Ur).all()
 
 
 def test_solve_golden_fixture_controls(dev, orc_golden):
