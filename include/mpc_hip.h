@@ -111,6 +111,12 @@ int mpc_eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *cl,
                        const int32_t *cl_index, const double *U, const double *y,
                        const double *Sigma, double *psi, double *grad, double *yhat, void *stream);
 
+/* the same evaluation by the wave-per-agent code of the persistent solve kernel (one wavefront per
+ * agent: wide rollout, stage k on lane k, adjoint on one lane) -- bit-identical results */
+int mpc_eval_cost_grad_wave(mpc_handle *h, int B, const double *x0, const double *cl,
+                            const int32_t *cl_index, const double *U, const double *y,
+                            const double *Sigma, double *psi, double *grad, double *yhat, void *stream);
+
 /* a-10, kernel K2: forward-backward step. p = clamp(-gamma*grad, lb-x, ub-x), xhat = x+p;
  * out[B][2] = [||p||^2, grad'p].  gamma[B]. */
 int mpc_prox_step(mpc_handle *h, int B, const double *x, const double *grad, const double *gamma,

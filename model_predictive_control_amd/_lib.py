@@ -26,6 +26,7 @@ EXPORTS = [
     "mpc_lbfgs_apply", "mpc_solve_batch", "mpc_closed_loop", "mpc_last_solve_info",
     "mpc_last_solve_info2", "mpc_math_probe", "mpc_set_groups", "mpc_last_kernel_ms", "mpc_lane_payoff",
     "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
+    "mpc_eval_cost_grad_wave",
 ]
 
 
@@ -92,6 +93,7 @@ def load():
     L.mpc_stage_errors.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     L.mpc_stage_cost.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     L.mpc_eval_cost_grad.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_eval_cost_grad_wave.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_prox_step.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_lbfgs_apply.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_solve_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]

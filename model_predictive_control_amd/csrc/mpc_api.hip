@@ -405,9 +405,24 @@ extern "C" int mpc_stage_cost(mpc_handle *h, int B, const double *x, const doubl
     return MPC_OK;
 }
 
+static int eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *cl, const int32_t *cl_index,
+                          const double *U, const double *y, const double *Sigma, double *psi, double *grad,
+                          double *yhat, void *stream, bool wave_path);
 extern "C" int mpc_eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *cl,
                                   const int32_t *cl_index, const double *U, const double *y,
                                   const double *Sigma, double *psi, double *grad, double *yhat, void *stream)
+{
+    return eval_cost_grad(h, B, x0, cl, cl_index, U, y, Sigma, psi, grad, yhat, stream, false);
+}
+extern "C" int mpc_eval_cost_grad_wave(mpc_handle *h, int B, const double *x0, const double *cl,
+                                       const int32_t *cl_index, const double *U, const double *y,
+                                       const double *Sigma, double *psi, double *grad, double *yhat, void *stream)
+{
+    return eval_cost_grad(h, B, x0, cl, cl_index, U, y, Sigma, psi, grad, yhat, stream, true);
+}
+static int eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *cl, const int32_t *cl_index,
+                          const double *U, const double *y, const double *Sigma, double *psi, double *grad,
+                          double *yhat, void *stream, bool wave_path)
 {
     int rc = check_common(h, B, "mpc_eval_cost_grad"); if (rc) return rc;
     if (B == 0) return MPC_OK;
@@ -425,7 +440,17 @@ extern "C" int mpc_eval_cost_grad(mpc_handle *h, int B, const double *x0, const 
     w.psi_direct = psi;
     Workspace saved = h->ws;
     h->ws = w;
-    launch_eval(h, h->ws, s, nullptr, nullptr, grad ? B : 0, grad ? 0 : B);
+    if (wave_path) {
+        // one wave per agent, the evaluation as the persistent kernel runs it (mpc_solo.hpp)
+        if (c.model == PAC) {
+            const size_t lds = sizeof(double) * solo_lds_doubles<PAC>(c.N, c.n, c.M, false);
+            hipLaunchKernelGGL(solo_eval_kernel<PAC>, dim3((unsigned)B), dim3(64), lds, s, c, h->ws, grad ? 1 : 0);
+        } else {
+            const size_t lds = sizeof(double) * solo_lds_doubles<KIN>(c.N, c.n, c.M, false);
+            hipLaunchKernelGGL(solo_eval_kernel<KIN>, dim3((unsigned)B), dim3(64), lds, s, c, h->ws, grad ? 1 : 0);
+        }
+    } else
+        launch_eval(h, h->ws, s, nullptr, nullptr, grad ? B : 0, grad ? 0 : B);
     h->ws = saved;
     HIPCHK(hipGetLastError());
     return MPC_OK;
@@ -592,9 +617,13 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     h->rounds = 0; h->evals_grad = 0; h->evals_cost = 0; h->eval_ms = 0.0; h->step_ms = 0.0;
     h->lbfgs_ms = 0.0; h->lbfgs_rows = 0; h->solo_agents = 0;
     for (int k = 0; k < 5; k++) { h->kernel_ms[k] = 0.0; h->kernel_launches[k] = 0; }
-    // an agent waits for at most ~(4 + 11 * 60) evaluations per inner iteration in the worst case;
-    // this bound only guards against a runaway loop
-    const long long max_rounds = 64LL * ((long long)c.max_total_inner + 16) + 1024;
+    // Guard against a runaway loop only: a valid solve must never reach it.  An inner iteration costs at
+    // most ~(4 + 11 * 60) evaluations (nine line-search trials whose quadratic-upper-bound loop doubles L
+    // up to L_max), an outer iteration a handful more; with an evaluation budget an agent stops at the
+    // first stop test past it.  Every running agent consumes at least one evaluation per round.
+    const long long per_iter = 700;
+    long long max_rounds = per_iter * ((long long)c.max_total_inner + 16) + 8LL * c.max_outer + 1024;
+    if (c.max_total_evals > 0) max_rounds = std::min(max_rounds, (long long)c.max_total_evals + per_iter + 8LL * c.max_outer + 1024);
     const bool solo_ok = h->solo_max > 0 && solo_fits(h);
     size_t nev = 0;               // events 0 .. nev-1 of the pool: five per sampled launch set
     bool solo_timed[MPC_MAX_GROUPS] = {false};

@@ -758,6 +758,7 @@ MPC_DEV double wrap_to_pi(const DevCfg &c, double ang)
 MPC_DEV void tracking_errors(const DevCfg &c, const Geom &g, double px, double py, double phi,
                              double &cte, double &he, double &pe)
 {
+#pragma clang fp contract(off)   // fixed roundings: the same bits in every kernel this is inlined into
     cte = (px - g.px_) * (g.ny_ - g.py_) - (py - g.py_) * (g.nx_ - g.px_);
     const double desired = m_atan2(g.qy_ - g.ny_, g.qx_ - g.nx_);
     he = wrap_to_pi(c, desired - phi);
@@ -769,14 +770,19 @@ template <int MODEL, bool GRAD>
 MPC_DEV double stage_cost(const DevCfg &c, const Geom &g, const double (&x)[ModelDim<MODEL>::NX],
                           double d, double dl, double (&xb)[ModelDim<MODEL>::NX], double (&ub)[2])
 {
+#pragma clang fp contract(off)   // fixed roundings: the same bits in every kernel this is inlined into
     double cte, he, pe;
     tracking_errors(c, g, x[0], x[1], x[2], cte, he, pe);
     double sp;
     if (MODEL == PAC) sp = sqrt(x[3] * x[3] + x[4] * x[4]);
     else sp = x[3];
     const double ev = sp - c.v_ref;
-    const double L = c.w[0] * ev * ev + c.w[1] * cte * cte + c.w[2] * pe * pe + c.w[3] * he * he +
-                     c.w[4] * dl * dl + c.w[5] * d * d;
+    double L = (c.w[0] * ev) * ev;
+    L = fma(c.w[1] * cte, cte, L);
+    L = fma(c.w[2] * pe, pe, L);
+    L = fma(c.w[3] * he, he, L);
+    L = fma(c.w[4] * dl, dl, L);
+    L = fma(c.w[5] * d, d, L);
     if (GRAD) {
         xb[0] += 2.0 * c.w[1] * cte * (g.ny_ - g.py_) + 2.0 * c.w[2] * pe * (g.qy_ - g.ny_);
         xb[1] += -2.0 * c.w[1] * cte * (g.nx_ - g.px_) - 2.0 * c.w[2] * pe * (g.qx_ - g.nx_);
@@ -798,6 +804,7 @@ template <int MODEL>
 MPC_DEV double stage_constraint(const DevCfg &c, const Geom &g,
                                 const double (&x)[ModelDim<MODEL>::NX], int i)
 {
+#pragma clang fp contract(off)
     if (c.constr_mode == 1) return x[i] * x[i] - c.g_off[i];
     const double wx = g.qx_ - g.nx_, wy = g.qy_ - g.ny_;
     const double pe = (x[0] - g.nx_) * wy - (x[1] - g.ny_) * wx;
@@ -809,6 +816,7 @@ MPC_DEV void stage_constraint_adjoint(const DevCfg &c, const Geom &g,
                                       const double (&x)[ModelDim<MODEL>::NX], int i, double yh,
                                       double (&xb)[ModelDim<MODEL>::NX])
 {
+#pragma clang fp contract(off)
     if (c.constr_mode == 1) { xb[i] += yh * 2.0 * x[i]; return; }
     const double wx = g.qx_ - g.nx_, wy = g.qy_ - g.ny_;
     const double nrm = sqrt(wx * wx + wy * wy);

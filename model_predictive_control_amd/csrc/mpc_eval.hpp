@@ -220,6 +220,107 @@ rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 // per (slot, stage) record written for gradient requests: dL/dx (NX), dL/du (2), T (NX x NX)
 template <int MODEL> struct JacRec { static constexpr int SIZE = ModelDim<MODEL>::NX * (ModelDim<MODEL>::NX + 1) + 2; };
 
+// K1b for one (request, stage): nearest point, stage cost, ALM terms and -- for gradient requests --
+// the stage's cost gradient and transition sensitivities.  `put(f, v)` stores field f of the stage
+// record: dL/dx (NX), dL/du (2), T (NX x NX), and field JS = the stage cost.  One body for the
+// two-kernel path (records in the slot-indexed scratch), the fused kernel and the persistent solo kernel
+// (records in LDS).  The cost arithmetic is written with fixed roundings (no contraction, explicit
+// fma): the same request must give the same bits whichever kernel this is inlined into.
+template <int MODEL, class Put>
+__device__ __forceinline__ void stage_record(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
+                                             int k, const double (&xs)[ModelDim<MODEL>::NX],
+                                             const double (&xe)[ModelDim<MODEL>::NX], double d, double dl,
+                                             const double *__restrict__ clp, Put put)
+{
+    constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
+    const int idx = nearest_index(c, clp, xe[0], xe[1]);
+    Geom g;
+    load_geom(c, clp, idx, g);
+    double xb[NX], ub[2] = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NX; i++) xb[i] = 0.0;
+    double L = is_g ? stage_cost<MODEL, true>(c, g, xe, d, dl, xb, ub)
+                    : stage_cost<MODEL, false>(c, g, xe, d, dl, xb, ub);
+    if (c.sm) {
+#pragma clang fp contract(off)
+        const size_t am = (size_t)a * c.m;
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            if (i < c.sm) {
+                const size_t kk = am + (size_t)(k * c.sm + i);
+                const double gv = stage_constraint<MODEL>(c, g, xe, i);
+                double lb, ubd;
+                constraint_bounds(c, i, lb, ubd);
+                const double sg = w.Sig[kk];
+                const double zeta = gv + w.y[kk] / sg;
+                const double zhat = fmax(lb, fmin(zeta, ubd));
+                const double dd = zeta - zhat;
+                const double yh = sg * dd;
+                L = fma(0.5 * dd, yh, L);
+                if (!ch2) w.yhe[kk] = yh;
+                if (is_g) stage_constraint_adjoint<MODEL>(c, g, xe, i, yh, xb);
+            }
+        }
+    }
+    put(JS, L);
+    if (is_g) {
+        StageInput<MODEL> u;
+        prep_input(c, d, dl, u);
+        double T[NX][NX];
+        stage_tangents<MODEL>(c, u, xs, T);
+#pragma unroll
+        for (int i = 0; i < NX; i++) put(i, xb[i]);
+        put(NX, ub[0]);
+        put(NX + 1, ub[1]);
+#pragma unroll
+        for (int dd = 0; dd < NX; dd++) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) put(NX + 2 + dd * NX + i, T[dd][i]);
+        }
+    }
+}
+
+// K1c for one request: psi = sum of stage costs (stage order, as main.py:36-40) and the adjoint
+// recursion over the stage records; `get(k, f)` reads field f of stage k.
+template <int MODEL, class Get>
+__device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g, Get get)
+{
+    constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE;
+    const int N = c.N, n = c.n;
+    double psi = 0.0;
+    for (int k = 0; k < N; k++) psi += get(k, JS);
+    if (w.psi_direct) w.psi_direct[a] = psi;
+    else if (!ch2) w.rec[(size_t)a * REC + R_PSIE] = psi;
+    if (!is_g) return;
+    double lam[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) lam[i] = 0.0;
+    double *grow = (ch2 ? w.ge2 : w.ge) + (size_t)a * n;
+    for (int k = N - 1; k >= 0; k--) {
+#pragma unroll
+        for (int i = 0; i < NX; i++) lam[i] += get(k, i);
+        double gu[2], lz[NZ];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            double acc = get(k, NX + jj);
+#pragma unroll
+            for (int i = 0; i < NX; i++) acc = fma(get(k, NX + 2 + (NZ + jj) * NX + i), lam[i], acc);
+            gu[jj] = acc;
+        }
+#pragma unroll
+        for (int jj = 0; jj < NZ; jj++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; i++) acc = fma(get(k, NX + 2 + jj * NX + i), lam[i], acc);
+            lz[jj] = acc;
+        }
+#pragma unroll
+        for (int jj = 0; jj < NZ; jj++) lam[2 + jj] = lz[jj];
+        grow[2 * k] = gu[0];
+        grow[2 * k + 1] = gu[1];
+    }
+}
+
 template <int MODEL, bool SHARED_CL>
 __global__ void __launch_bounds__(64)
 stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
@@ -244,57 +345,17 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
     }
     const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
     const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
-    const int idx = nearest_index(c, clp, xe[0], xe[1]);
-    Geom g;
-    load_geom(c, clp, idx, g);
-    double xb[NX], ub[2] = {0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < NX; i++) xb[i] = 0.0;
-    double L = is_g ? stage_cost<MODEL, true>(c, g, xe, d, dl, xb, ub)
-                    : stage_cost<MODEL, false>(c, g, xe, d, dl, xb, ub);
-    if (c.sm) {
-        const size_t am = (size_t)a * c.m;
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-            if (i < c.sm) {
-                const size_t kk = am + (size_t)(k * c.sm + i);
-                const double gv = stage_constraint<MODEL>(c, g, xe, i);
-                double lb, ubd;
-                constraint_bounds(c, i, lb, ubd);
-                const double sg = w.Sig[kk];
-                const double zeta = gv + w.y[kk] / sg;
-                const double zhat = fmax(lb, fmin(zeta, ubd));
-                const double dd = zeta - zhat;
-                const double yh = sg * dd;
-                L += 0.5 * dd * yh;
-                if (!ch2) w.yhe[kk] = yh;
-                if (is_g) stage_constraint_adjoint<MODEL>(c, g, xe, i, yh, xb);
-            }
-        }
-    }
-    w.stage_L[(size_t)k * St + uslot] = L;
-    if (!is_g) return;
-    StageInput<MODEL> u;
-    prep_input(c, d, dl, u);
-    double T[NX][NX];
-    stage_tangents<MODEL>(c, u, xs, T);
-    double *jr = w.jac + (size_t)k * JS * St + uslot;
-#pragma unroll
-    for (int i = 0; i < NX; i++) jr[(size_t)i * St] = xb[i];
-    jr[(size_t)NX * St] = ub[0];
-    jr[(size_t)(NX + 1) * St] = ub[1];
-#pragma unroll
-    for (int dd = 0; dd < NX; dd++) {
-#pragma unroll
-        for (int i = 0; i < NX; i++) jr[(size_t)(NX + 2 + dd * NX + i) * St] = T[dd][i];
-    }
+    double *const jr = w.jac + (size_t)k * JS * St + uslot;
+    double *const sl = w.stage_L + (size_t)k * St + uslot;
+    stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp,
+                        [=](int f, double v) { if (f == JS) *sl = v; else jr[(size_t)f * St] = v; });
 }
 
 template <int MODEL>
 __global__ void __launch_bounds__(64)
 adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm)
 {
-    constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE;
+    constexpr int JS = JacRec<MODEL>::SIZE;
     const SlotMap sm(counts, nG_imm, nC_imm);
     const int sb = blockIdx.x;
     if (sb >= sm.nblk) return;
@@ -302,43 +363,11 @@ adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts
     const int uslot = sb * 64 + threadIdx.x;
     const int raw = w.agent_of[uslot];
     if (raw < 0) return;
-    const int a = raw & AGENT_MASK;
-    const bool ch2 = (raw & CH2_BIT) != 0;
     const size_t St = (size_t)w.St;
-    const int N = c.N, n = c.n;
-    double psi = 0.0;
-    for (int k = 0; k < N; k++) psi += w.stage_L[(size_t)k * St + uslot]; // stage order, as main.py:36-40
-    if (w.psi_direct) w.psi_direct[a] = psi;
-    else if (!ch2) w.rec[(size_t)a * REC + R_PSIE] = psi;
-    if (!is_g) return;
-    double lam[NX];
-#pragma unroll
-    for (int i = 0; i < NX; i++) lam[i] = 0.0;
-    double *grow = (ch2 ? w.ge2 : w.ge) + (size_t)a * n;
-    for (int k = N - 1; k >= 0; k--) {
-        const double *jr = w.jac + (size_t)k * JS * St + uslot;
-#pragma unroll
-        for (int i = 0; i < NX; i++) lam[i] += jr[(size_t)i * St];
-        double gu[2], lz[NZ];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            double acc = jr[(size_t)(NX + j) * St];
-#pragma unroll
-            for (int i = 0; i < NX; i++) acc += jr[(size_t)(NX + 2 + (NZ + j) * NX + i) * St] * lam[i];
-            gu[j] = acc;
-        }
-#pragma unroll
-        for (int j = 0; j < NZ; j++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; i++) acc += jr[(size_t)(NX + 2 + j * NX + i) * St] * lam[i];
-            lz[j] = acc;
-        }
-#pragma unroll
-        for (int j = 0; j < NZ; j++) lam[2 + j] = lz[j];
-        grow[2 * k] = gu[0];
-        grow[2 * k + 1] = gu[1];
-    }
+    const double *const jac = w.jac + uslot, *const sl = w.stage_L + uslot;
+    adjoint_rec<MODEL>(c, w, raw & AGENT_MASK, (raw & CH2_BIT) != 0, is_g, [=](int k, int f) {
+        return f == JS ? sl[(size_t)k * St] : jac[((size_t)k * JS + f) * St];
+    });
 }
 
 // K1b + K1c in one launch: a workgroup takes SPB = BLK / N consecutive slots; thread (k, j) does stage
@@ -348,106 +377,6 @@ adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts
 // HBM and one launch per round disappears.  Threads are stage-major (j fastest), so a wave reads
 // SPB consecutive slots per stage from the slot-indexed scratch.
 template <int MODEL> struct FusedBlk { static constexpr int BLK = MODEL == PAC ? 128 : 256; };
-
-// K1b for one (request, stage): nearest point, stage cost, ALM terms and -- for gradient requests --
-// the stage's cost gradient and transition sensitivities, left as a record in LDS: field f of the
-// record at r[f * NS] (fields: dL/dx (NX), dL/du (2), T (NX x NX); field JS = the stage cost).  Shared
-// by stage_adjoint_kernel and the persistent solo kernel.
-template <int MODEL>
-__device__ __forceinline__ void stage_record_lds(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
-                                                 int k, const double (&xs)[ModelDim<MODEL>::NX],
-                                                 const double (&xe)[ModelDim<MODEL>::NX], double d, double dl,
-                                                 const double *__restrict__ clp, double *r, int NS)
-{
-    constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
-    const int idx = nearest_index(c, clp, xe[0], xe[1]);
-    Geom g;
-    load_geom(c, clp, idx, g);
-    double xb[NX], ub[2] = {0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < NX; i++) xb[i] = 0.0;
-    double L = is_g ? stage_cost<MODEL, true>(c, g, xe, d, dl, xb, ub)
-                    : stage_cost<MODEL, false>(c, g, xe, d, dl, xb, ub);
-    if (c.sm) {
-        const size_t am = (size_t)a * c.m;
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-            if (i < c.sm) {
-                const size_t kk = am + (size_t)(k * c.sm + i);
-                const double gv = stage_constraint<MODEL>(c, g, xe, i);
-                double lb, ubd;
-                constraint_bounds(c, i, lb, ubd);
-                const double sg = w.Sig[kk];
-                const double zeta = gv + w.y[kk] / sg;
-                const double zhat = fmax(lb, fmin(zeta, ubd));
-                const double dd = zeta - zhat;
-                const double yh = sg * dd;
-                L += 0.5 * dd * yh;
-                if (!ch2) w.yhe[kk] = yh;
-                if (is_g) stage_constraint_adjoint<MODEL>(c, g, xe, i, yh, xb);
-            }
-        }
-    }
-    r[(size_t)JS * NS] = L;
-    if (is_g) {
-        StageInput<MODEL> u;
-        prep_input(c, d, dl, u);
-        double T[NX][NX];
-        stage_tangents<MODEL>(c, u, xs, T);
-#pragma unroll
-        for (int i = 0; i < NX; i++) r[(size_t)i * NS] = xb[i];
-        r[(size_t)NX * NS] = ub[0];
-        r[(size_t)(NX + 1) * NS] = ub[1];
-#pragma unroll
-        for (int dd = 0; dd < NX; dd++) {
-#pragma unroll
-            for (int i = 0; i < NX; i++) r[(size_t)(NX + 2 + dd * NX + i) * NS] = T[dd][i];
-        }
-    }
-}
-
-// K1c for one request out of the LDS records: psi = sum of stage costs (stage order, as main.py:36-40)
-// and the adjoint recursion; `rec` points at the request's stage-0 record, stage k at rec + k * SK.
-template <int MODEL>
-__device__ __forceinline__ void adjoint_from_lds(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
-                                                 const double *rec, int SK, int NS)
-{
-    constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE;
-    const int N = c.N, n = c.n;
-    double psi = 0.0;
-    for (int k = 0; k < N; k++) psi += rec[(size_t)JS * NS + k * SK];
-    if (w.psi_direct) w.psi_direct[a] = psi;
-    else if (!ch2) w.rec[(size_t)a * REC + R_PSIE] = psi;
-    if (!is_g) return;
-    double lam[NX];
-#pragma unroll
-    for (int i = 0; i < NX; i++) lam[i] = 0.0;
-    double *grow = (ch2 ? w.ge2 : w.ge) + (size_t)a * n;
-    for (int k = N - 1; k >= 0; k--) {
-        const double *jr = rec + k * SK;
-#pragma unroll
-        for (int i = 0; i < NX; i++) lam[i] += jr[(size_t)i * NS];
-        double gu[2], lz[NZ];
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            double acc = jr[(size_t)(NX + jj) * NS];
-#pragma unroll
-            for (int i = 0; i < NX; i++) acc += jr[(size_t)(NX + 2 + (NZ + jj) * NX + i) * NS] * lam[i];
-            gu[jj] = acc;
-        }
-#pragma unroll
-        for (int jj = 0; jj < NZ; jj++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; i++) acc += jr[(size_t)(NX + 2 + jj * NX + i) * NS] * lam[i];
-            lz[jj] = acc;
-        }
-#pragma unroll
-        for (int jj = 0; jj < NZ; jj++) lam[2 + jj] = lz[jj];
-        grow[2 * k] = gu[0];
-        grow[2 * k + 1] = gu[1];
-    }
-}
 
 template <int MODEL, bool SHARED_CL>
 __global__ void __launch_bounds__(FusedBlk<MODEL>::BLK, 2)
@@ -477,7 +406,8 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
             }
             const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
             const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
-            stage_record_lds<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, s_rec + k * SPB + j, NS);
+            double *const r = s_rec + k * SPB + j;
+            stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, [=](int f, double v) { r[(size_t)f * NS] = v; });
         }
     }
     __syncthreads();
@@ -485,7 +415,9 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
     const int j = threadIdx.x, uslot = slot0 + j;
     const int raw = uslot < nslots ? w.agent_of[uslot] : -1;
     if (raw < 0) return;
-    adjoint_from_lds<MODEL>(c, w, raw & AGENT_MASK, (raw & CH2_BIT) != 0, uslot < sm.gpad, s_rec + j, SPB, NS);
+    const double *const rj = s_rec + j;
+    adjoint_rec<MODEL>(c, w, raw & AGENT_MASK, (raw & CH2_BIT) != 0, uslot < sm.gpad,
+                       [=](int k, int f) { return rj[(size_t)f * NS + k * SPB]; });
 }
 
 } // namespace mpc

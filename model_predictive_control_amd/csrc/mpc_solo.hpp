@@ -13,7 +13,7 @@
 // The evaluation inside the wave reuses the device functions of the round path with the same
 // roundings -- the wave-per-request rollout (kin_wide_rollout) for the kinematic model, the
 // thread-per-agent stage_forward on one lane otherwise; stage k of the horizon on lane k
-// (stage_record_lds); the adjoint recursion on one lane (adjoint_from_lds) -- so an agent gets the
+// (stage_record); the adjoint recursion on one lane (adjoint_rec) -- so an agent gets the
 // same bits whichever path serves it, and the host may switch on the live request counts.
 // Speculative gradients are not issued here (two evaluations of one agent run one after the other in
 // its wave, so a speculation can only lose); one that is pending when the agent arrives is consumed.
@@ -69,10 +69,11 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
 #pragma unroll
         for (int i = 0; i < NX; i++) { xs[i] = traj[lane * NX + i]; xe[i] = traj[(lane + 1) * NX + i]; }
         const double *__restrict__ clp = w.cl_index ? w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S : w.cl;
-        stage_record_lds<MODEL>(c, w, a, ch2, is_g, lane, xs, xe, d, dl, clp, rec + lane, N);
+        double *const r = rec + lane;
+        stage_record<MODEL>(c, w, a, ch2, is_g, lane, xs, xe, d, dl, clp, [=](int f, double v) { r[f * N] = v; });
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) adjoint_from_lds<MODEL>(c, w, a, ch2, is_g, rec, 1, N);
+    if (lane == 0) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rec[f * N + k]; });
 }
 
 // list of the agents of this view that are still running (phase != PH_DONE), in agent order inside a
@@ -87,6 +88,16 @@ __global__ void __launch_bounds__(256) solo_list_kernel(const Workspace w, int *
     if (lane == 0 && bal != 0ull) base = atomicAdd(&ctr[1], __popcll(bal));
     base = __builtin_amdgcn_readfirstlane(base);
     if (on) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = a;
+}
+
+// K1 alone through the wave-per-agent evaluation (standalone entry point, parity tests): agent = block
+template <int MODEL>
+__global__ void __launch_bounds__(64, 1) solo_eval_kernel(const DevCfg c, const Workspace w, int want_grad)
+{
+    extern __shared__ double s_solo[];
+    double *traj = s_solo;
+    double *rec = traj + (size_t)(c.N + 1) * ModelDim<MODEL>::NX;
+    solo_eval<MODEL>(c, w, blockIdx.x, threadIdx.x, false, want_grad != 0, traj, rec);
 }
 
 // ctr[0] = claim counter, ctr[1] = number of list entries (list == nullptr: every agent of the view)

@@ -213,6 +213,7 @@ __device__ __forceinline__ void strow(double *__restrict__ p, int n, int lane, c
 
 __device__ __forceinline__ double prox_p(const DevCfg &c, int par, double x, double g, double gamma)
 {
+#pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     // comparison-selects, not fmin/fmax: a NaN gradient must stay a NaN step (Eigen's cwiseMax/cwiseMin
     // in alpaqa's projection keep it too), so that ||p||/gamma is NaN and the stop test says NotFinite
     const double lo = c.u_lb[par] - x, hi = c.u_ub[par] - x;
@@ -222,6 +223,7 @@ __device__ __forceinline__ double prox_p(const DevCfg &c, int par, double x, dou
 }
 __device__ __forceinline__ bool in_J(const DevCfg &c, int par, double x, double g, double gamma)
 {
+#pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     const double gd = x - gamma * g;
     return !(gd < c.u_lb[par] || c.u_ub[par] < gd);
 }
@@ -232,13 +234,14 @@ __device__ __forceinline__ void prox_to_xe(const DevCfg &c, double *__restrict__
                                            const Row<NE> &xb, const Row<NE> &gb, double gamma,
                                            double &pp, double &gp)
 {
+#pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     Row<NE> xh;
     double a = 0.0, b = 0.0;
 #pragma unroll
     for (int e = 0; e < NE; e++) {
         const double p = prox_p(c, lane & 1, xb.v[e], gb.v[e], gamma);
         xh.v[e] = xb.v[e] + p;
-        if (lane + 64 * e < n) { a += p * p; b += gb.v[e] * p; }
+        if (lane + 64 * e < n) { a = fma(p, p, a); b = fma(gb.v[e], p, b); }
     }
     strow<NE>(xe, n, lane, xh);
     wave_sum2(a, b);
@@ -282,6 +285,7 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
                                                const bool (&inj)[NE], int lidx, int lfull,
                                                Row<NE> &q, int &rows_read)
 {
+#pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     const int M = c.M;
     const int cnt = lfull ? M : lidx;
     if (cnt == 0) return false;
@@ -305,18 +309,18 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
     auto first_loop = [&](int t, const Row<NE> &s, const Row<NE> &y) {
         double sy = 0.0, sq = 0.0;
 #pragma unroll
-        for (int e = 0; e < NE; e++) { sy += s.v[e] * y.v[e]; sq += s.v[e] * q.v[e]; }
+        for (int e = 0; e < NE; e++) { sy = fma(s.v[e], y.v[e], sy); sq = fma(s.v[e], q.v[e], sq); }
         wave_sum2(sy, sq);
         const double rho = fast_rcp(sy);
         if (!(rho > 0.0)) return;          // lane t keeps rho_t = -1
         const double al = rho * sq;
         if (lane == t) { rho_v = rho; alpha_v = al; }
 #pragma unroll
-        for (int e = 0; e < NE; e++) q.v[e] -= al * y.v[e];
+        for (int e = 0; e < NE; e++) q.v[e] = fma(-al, y.v[e], q.v[e]);
         if (h0 < 0.0) { // y'y is only needed once, for H0 of the newest valid pair (wave-uniform branch)
             double yy = 0.0;
 #pragma unroll
-            for (int e = 0; e < NE; e++) yy += y.v[e] * y.v[e];
+            for (int e = 0; e < NE; e++) yy = fma(y.v[e], y.v[e], yy);
             h0 = 1.0 / (rho * wave_sum(yy));
         }
     };
@@ -325,11 +329,11 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
         if (!(rho > 0.0)) return;
         double yq = 0.0;
 #pragma unroll
-        for (int e = 0; e < NE; e++) yq += y.v[e] * q.v[e];
+        for (int e = 0; e < NE; e++) yq = fma(y.v[e], q.v[e], yq);
         yq = wave_sum(yq);
         const double ab = rdlane(alpha_v, t) - rho * yq;
 #pragma unroll
-        for (int e = 0; e < NE; e++) q.v[e] += ab * s.v[e];
+        for (int e = 0; e < NE; e++) q.v[e] = fma(ab, s.v[e], q.v[e]);
     };
     auto load_masked = [&](int t, Row<NE> &s, Row<NE> &y) {
         int i = lidx - 1 - t; if (i < 0) i += M;
@@ -389,6 +393,7 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
 __device__ __forceinline__ void update_penalty(const DevCfg &c, const Workspace &w, size_t am, int lane,
                                                double Delta, int first, double ne1)
 {
+#pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     for (int k = lane; k < c.m; k += 64) {
         const double so = w.Sig_old[am + k];
         double sv = so;
@@ -425,6 +430,7 @@ template <int NE, int MC>
 __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lane, const AgentIn<NE> &in,
                              double *hist, bool hist_ready, bool allow_spec = true)
 {
+#pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     const int n = c.n, m = c.m;
     const size_t an = (size_t)a * n, am = (size_t)a * m;
     double *recp = w.rec + (size_t)a * REC;
@@ -797,7 +803,9 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             const double ls_cond = phin - (phik - sigpp);
             const double margin = (1.0 + fabs(phik)) * c.qub_tol;
             tau /= 2.0;
-            if (ls_cond > margin && tau >= c.tau_min) { phase = PH_LS_TRIAL; spec = 0; break; }
+            // (written so that a NaN condition -- a trial point whose evaluation overflowed -- counts as a
+            // failed trial like +inf does, instead of being accepted because NaN compares false)
+            if (!(ls_cond <= margin) && tau >= c.tau_min) { phase = PH_LS_TRIAL; spec = 0; break; }
             // accept x+ : L-BFGS update with (x+ - x, grad+ - grad)
             if (gamma != gamman) { lidx = 0; lfull = 0; }
             {

@@ -125,8 +125,9 @@ class BatchedMPC:
                                            _ptr(out), self._stream()))
         return out
 
-    def eval_cost_grad(self, x0, centerline, U, y=None, Sigma=None, cl_index=None, want_grad=True):
-        """K1: psi[B], grad[B, 2N] (or None), yhat[B, m] (or None)."""
+    def eval_cost_grad(self, x0, centerline, U, y=None, Sigma=None, cl_index=None, want_grad=True, wave=False):
+        """K1: psi[B], grad[B, 2N] (or None), yhat[B, m] (or None).  wave=True: the wave-per-agent
+        evaluation of the persistent solve kernel instead of the K1a/K1b/K1c launches (same bits)."""
         B = x0.shape[0]
         self._chk(x0, (B, self.nx), "x0"); self._chk(U, (B, self.n), "U")
         cl = self._centerline(centerline, cl_index, B)
@@ -137,9 +138,9 @@ class BatchedMPC:
         psi = self._empty(B)
         grad = self._empty(B, self.n) if want_grad else None
         yhat = self._empty(B, self.m) if self.m else None
-        _lib.check(self.lib.mpc_eval_cost_grad(self._h, B, _ptr(x0), _ptr(cl), _ptr(cl_index), _ptr(U),
-                                               _ptr(y), _ptr(Sigma), _ptr(psi), _ptr(grad), _ptr(yhat),
-                                               self._stream()))
+        fn = self.lib.mpc_eval_cost_grad_wave if wave else self.lib.mpc_eval_cost_grad
+        _lib.check(fn(self._h, B, _ptr(x0), _ptr(cl), _ptr(cl_index), _ptr(U), _ptr(y), _ptr(Sigma), _ptr(psi),
+                      _ptr(grad), _ptr(yhat), self._stream()))
         return psi, grad, yhat
 
     # ------------------------------------------------------------------ solver pieces

@@ -734,7 +734,9 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
             phin = psin + ppn / (2.0 * gamman) + gpn;
             ls_cond = phin - (phik - sig_pp);
             tau /= 2.0;
-        } while (ls_cond > margin && tau >= c->tau_min);
+            /* a NaN condition (the trial point's evaluation overflowed) is a failed trial, like +inf:
+             * alpaqa's literal `ls_cond > margin` would accept it because NaN compares false */
+        } while (!(ls_cond <= margin) && tau >= c->tau_min);
 
         if (gamma != gamman) lbfgs_reset(lb);
         lbfgs_update(lb, xk, xn, gk, gn);

