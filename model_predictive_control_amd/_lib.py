@@ -26,7 +26,7 @@ EXPORTS = [
     "mpc_lbfgs_apply", "mpc_solve_batch", "mpc_closed_loop", "mpc_last_solve_info",
     "mpc_last_solve_info2", "mpc_math_probe", "mpc_set_groups", "mpc_last_kernel_ms", "mpc_lane_payoff",
     "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
-    "mpc_eval_cost_grad_wave",
+    "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks",
 ]
 
 
@@ -110,6 +110,8 @@ def load():
     L.mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.mpc_last_kernel_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpc_set_solo_max.argtypes = [vp, ci]
+    L.mpc_centerline_blocks.argtypes = [vp, vp, ci, vp]
+    L.mpc_set_nearest_blocks.argtypes = [vp, ci]
     for name in EXPORTS:
         if name != "mpc_last_error":
             getattr(L, name).restype = ci

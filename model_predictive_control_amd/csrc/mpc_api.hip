@@ -36,6 +36,13 @@ struct mpc_handle {
     int fused_max = 16384;      // ... while a round holds at most this many requests (MPC_FUSED_MAX)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
     int num_cus = 256;
+    // block bounding boxes of the centerline table last handed to mpc_centerline_blocks
+    double *cl_boxes = nullptr;
+    size_t cl_boxes_bytes = 0;
+    const double *cl_boxes_for = nullptr; // the table they describe (device pointer identity)
+    int cl_boxes_rows = 0;
+    bool nearest_blocks = false;          // MPC_NEAREST_BLOCKS / mpc_set_nearest_blocks: the pruned search (same
+                                          // index; measured slower than the full scan: profiles/r02_nearest_blocks.txt)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
                                 // wave-per-agent kernel (MPC_SOLO_MAX; 0 = rounds only)
     int Bp_alloc = 0;      // workspace capacity (agents)
@@ -178,6 +185,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
     if (getenv("MPC_SOLO_MAX")) h->solo_max = atoi(getenv("MPC_SOLO_MAX"));
+    h->nearest_blocks = getenv("MPC_NEAREST_BLOCKS") != nullptr;
     h->cfg = *cfg;
     int rc = make_devcfg(*cfg, h->dc);
     if (rc) { delete h; return rc; }
@@ -203,6 +211,7 @@ extern "C" int mpc_destroy(mpc_handle *h)
     (void)hipSetDevice(h->device);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->cl_boxes) (void)hipFree(h->cl_boxes);
     if (h->host_counts) (void)hipHostFree(h->host_counts);
     for (auto ev : h->ev_pool) (void)hipEventDestroy(ev);
     for (int g = 0; g < MPC_MAX_GROUPS; g++) if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
@@ -329,6 +338,32 @@ static int check_common(mpc_handle *h, int B, const char *who)
     return MPC_OK;
 }
 
+// the boxes to use with centerline table `cl` (null: none prepared for it, or switched off)
+static const double *boxes_for(const mpc_handle *h, const double *cl)
+{
+    return (h->nearest_blocks && h->cl_boxes && h->cl_boxes_for == cl) ? h->cl_boxes : nullptr;
+}
+
+extern "C" int mpc_centerline_blocks(mpc_handle *h, const double *cl, int C, void *stream)
+{
+    int rc = check_common(h, C, "mpc_centerline_blocks"); if (rc) return rc;
+    h->cl_boxes_for = nullptr; h->cl_boxes_rows = 0;
+    if (C == 0 || !cl) return MPC_OK;
+    const DevCfg &c = h->dc;
+    const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
+    if (NB > 64) return MPC_OK;           // the search keeps one bit per block: longer tables take the full scan
+    const size_t bytes = sizeof(double) * 4 * (size_t)NB * (size_t)C;
+    if (bytes > h->cl_boxes_bytes) {
+        if (h->cl_boxes) { HIPCHK(hipFree(h->cl_boxes)); h->cl_boxes = nullptr; h->cl_boxes_bytes = 0; }
+        if (hipMalloc((void **)&h->cl_boxes, bytes) != hipSuccess) return fail(MPC_E_ALLOC, "centerline block table hipMalloc failed");
+        h->cl_boxes_bytes = bytes;
+    }
+    hipLaunchKernelGGL(cl_blocks_kernel, grid_for(C * NB, 256), dim3(256), 0, (hipStream_t)stream, c, cl, C, h->cl_boxes);
+    HIPCHK(hipGetLastError());
+    h->cl_boxes_for = cl; h->cl_boxes_rows = C;
+    return MPC_OK;
+}
+
 extern "C" int mpc_rhs(mpc_handle *h, int B, const double *x, const double *u, double *dx, void *stream)
 {
     int rc = check_common(h, B, "mpc_rhs"); if (rc) return rc;
@@ -361,7 +396,7 @@ extern "C" int mpc_stage_errors(mpc_handle *h, int B, const double *pose, const 
     if (B == 0) return MPC_OK;
     if (!pose || !cl || !err) return fail(MPC_E_ARG, "mpc_stage_errors: null buffer");
     hipLaunchKernelGGL(errors_kernel, grid_for(B, 64), dim3(64), 0, (hipStream_t)stream, h->dc, B, pose, cl,
-                       cl_index, err, idx);
+                       cl_index, boxes_for(h, cl), err, idx);
     HIPCHK(hipGetLastError());
     return MPC_OK;
 }
@@ -433,7 +468,7 @@ static int eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *
     hipStream_t s = (hipStream_t)stream;
     // direct mode: the kernel reads and writes the caller's agent-major buffers in place
     Workspace w = h->ws;
-    w.cl = cl; w.cl_index = cl_index; w.x0 = x0;
+    w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.cl_boxes = boxes_for(h, cl);
     w.xe = const_cast<double *>(U); w.ge = grad ? grad : h->ws.ws_ge;
     w.y = const_cast<double *>(y); w.Sig = c.m ? const_cast<double *>(Sigma) : h->ws.ws_Sig;
     w.yhe = (yhat && c.m) ? yhat : h->ws.ws_yhe;
@@ -811,6 +846,7 @@ extern "C" int mpc_solve_batch(mpc_handle *h, int B, const double *x0, const dou
     hipStream_t s = (hipStream_t)stream;
     Workspace &w = h->ws;
     w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.xo = U; w.y = lambda; w.psi_direct = nullptr;
+    w.cl_boxes = boxes_for(h, cl);
     w.xe = w.ws_xe; w.ge = w.ws_ge; w.yhe = w.ws_yhe; w.Sig = w.ws_Sig;
     rc = run_solver(h, s); if (rc) return rc;
     if (stats) hipLaunchKernelGGL(stats_kernel, grid_for(B, 256), dim3(256), 0, s, w, stats);
@@ -891,6 +927,13 @@ extern "C" int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *laun
         if (launches5) launches5[k] = h->kernel_launches[k];
     }
     if (solo_agents) *solo_agents = h->solo_agents;
+    return MPC_OK;
+}
+
+extern "C" int mpc_set_nearest_blocks(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_set_nearest_blocks: null handle");
+    h->nearest_blocks = on != 0;
     return MPC_OK;
 }
 

@@ -40,16 +40,40 @@ __global__ void __launch_bounds__(64) simulate_kernel(const DevCfg c, int B, int
     }
 }
 
-// a-4/a-5 standalone
+// bounding boxes of the blocks of NEAR_BLK consecutive candidate points of every centerline
+// row (candidates are the points 0 .. S-2): boxes[row][block] = [xlo, xhi, ylo, yhi]
+__global__ void cl_blocks_kernel(const DevCfg c, const double *__restrict__ cl, int C, double *__restrict__ boxes)
+{
+    const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * NB) return;
+    const int row = t / NB, b = t - row * NB;
+    const double *x = cl + (size_t)row * 2 * (size_t)c.S, *y = x + c.S;
+    const int i0 = b * NEAR_BLK, i1 = min(i0 + NEAR_BLK, c.S - 1);
+    double xlo = x[i0], xhi = x[i0], ylo = y[i0], yhi = y[i0];
+    for (int i = i0 + 1; i < i1; i++) {
+        xlo = fmin(xlo, x[i]); xhi = fmax(xhi, x[i]); ylo = fmin(ylo, y[i]); yhi = fmax(yhi, y[i]);
+    }
+    double *q = boxes + 4 * (size_t)t;
+    q[0] = xlo; q[1] = xhi; q[2] = ylo; q[3] = yhi;
+}
+
+// a-4/a-5 standalone (boxes: the block boxes of the table, or null for the full scan)
 __global__ void errors_kernel(const DevCfg c, int B, const double *__restrict__ pose,
                               const double *__restrict__ cl, const int *__restrict__ cl_index,
-                              double *__restrict__ err, int *__restrict__ idx_out)
+                              const double *__restrict__ boxes, double *__restrict__ err, int *__restrict__ idx_out)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= B) return;
-    const double *clp = cl + (size_t)(cl_index ? cl_index[a] : 0) * 2 * (size_t)c.S;
-    const double px = pose[(size_t)a * 3], py = pose[(size_t)a * 3 + 1], phi = pose[(size_t)a * 3 + 2];
-    const int idx = nearest_index(c, clp, px, py);
+    // (no early return: the block search's loop is wave-uniform; lanes past the batch redo agent 0)
+    const bool live = a < B;
+    const int aa = live ? a : 0;
+    const int row = cl_index ? cl_index[aa] : 0;
+    const double *clp = cl + (size_t)row * 2 * (size_t)c.S;
+    const double px = pose[(size_t)aa * 3], py = pose[(size_t)aa * 3 + 1], phi = pose[(size_t)aa * 3 + 2];
+    const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
+    const int idx = boxes ? nearest_index_blocks(c, clp, boxes + (size_t)row * NB * 4, px, py)
+                          : nearest_index(c, clp, px, py);
+    if (!live) return;
     Geom g;
     load_geom(c, clp, idx, g);
     double cte, he, pe;

@@ -692,22 +692,26 @@ MPC_DEV void stage_tangents(const DevCfg &c, const StageInput<MODEL> &u,
 // ---------------------------------------------------------------------------------- tracking
 // car_dynamics.py:174-192: start at point 0, candidates 1..S-2, strict <.  Squared distances are
 // compared (sqrt is monotone).  cl is the flat row [x_0..x_{S-1}, y_0..y_{S-1}].
+// The squared distance is ONE fixed expression, fma(dx, dx, dy * dy), wherever it is formed: the
+// block-pruned search below must reproduce the full scan's argmin bit for bit.
+MPC_DEV double dist2(double cx, double cy, double px, double py)
+{
+#pragma clang fp contract(off)
+    const double dx = cx - px, dy = cy - py;
+    return fma(dx, dx, dy * dy);
+}
+
 MPC_DEV int nearest_index(const DevCfg &c, const double *__restrict__ cl, double px, double py)
 {
     const int S = c.S;
-    double dx = cl[0] - px, dy = cl[S] - py;
-    double best = dx * dx + dy * dy;
+    double best = dist2(cl[0], cl[S], px, py);
     int idx = 0;
     int i = 1;
     // four candidates per trip: their distances are independent (ILP for a lone wave); the
     // in-order strict "<" of the reference is kept by resolving ties towards the lower index
     for (; i + 3 < S - 1; i += 4) {
-        const double ax = cl[i] - px, ay = cl[S + i] - py;
-        const double bx = cl[i + 1] - px, by = cl[S + i + 1] - py;
-        const double ex = cl[i + 2] - px, ey = cl[S + i + 2] - py;
-        const double fx = cl[i + 3] - px, fy = cl[S + i + 3] - py;
-        const double d0 = ax * ax + ay * ay, d1 = bx * bx + by * by;
-        const double d2 = ex * ex + ey * ey, d3 = fx * fx + fy * fy;
+        const double d0 = dist2(cl[i], cl[S + i], px, py), d1 = dist2(cl[i + 1], cl[S + i + 1], px, py);
+        const double d2 = dist2(cl[i + 2], cl[S + i + 2], px, py), d3 = dist2(cl[i + 3], cl[S + i + 3], px, py);
         const bool l01 = d1 < d0, l23 = d3 < d2;
         const double m01 = l01 ? d1 : d0, m23 = l23 ? d3 : d2;
         const int i01 = l01 ? i + 1 : i, i23 = l23 ? i + 3 : i + 2;
@@ -719,11 +723,59 @@ MPC_DEV int nearest_index(const DevCfg &c, const double *__restrict__ cl, double
         idx = lt ? iq : idx;
     }
     for (; i < S - 1; i++) {
-        dx = cl[i] - px; dy = cl[S + i] - py;
-        const double d2 = dx * dx + dy * dy;
+        const double d2 = dist2(cl[i], cl[S + i], px, py);
         const bool lt = d2 < best;
         best = lt ? d2 : best;
         idx = lt ? i : idx;
+    }
+    return idx;
+}
+
+// the same argmin without looking at every point.  The candidates 0 .. S-2 are cut into
+// blocks of NEAR_BLK consecutive points whose bounding boxes [xlo, xhi, ylo, yhi] are computed once per
+// centerline row (cl_blocks_kernel).  (1) the first point of every block is a candidate like any
+// other: the best of them bounds the minimum from above; (2) a block whose box is farther than that
+// bound cannot hold the minimum -- the box distance is formed by the same expression as a point
+// distance and rounding is monotone, so "cannot" holds bit for bit; (3) the remaining blocks (one or
+// two on a smooth track) are scanned, each lane walking ITS OWN blocks through per-lane loads, so a
+// wave of cars spread along the track does not pay for the union of their neighbourhoods.  Ties go
+// to the lower index, as the reference's in-order strict "<" does.
+constexpr int NEAR_BLK = 8;
+MPC_DEV int nearest_index_blocks(const DevCfg &c, const double *__restrict__ cl, const double *__restrict__ bx,
+                                 double px, double py)
+{
+#pragma clang fp contract(off)
+    const int S = c.S, nc = S - 1, NB = (nc + NEAR_BLK - 1) / NEAR_BLK;
+    double best = dist2(cl[0], cl[S], px, py);
+    int idx = 0;
+    for (int b = 1; b < NB; b++) {                       // (1) block heads, in index order: strict "<" keeps ties low
+        const int i = b * NEAR_BLK;
+        const double d = dist2(cl[i], cl[S + i], px, py);
+        const bool lt = d < best;
+        best = lt ? d : best;
+        idx = lt ? i : idx;
+    }
+    unsigned long long mask = 0ull;
+    for (int b = 0; b < NB; b++) {                       // (2) boxes that can still hold the minimum
+        const double *q = bx + 4 * b;
+        const double ex = fmax(fmax(q[0] - px, px - q[1]), 0.0), ey = fmax(fmax(q[2] - py, py - q[3]), 0.0);
+        const double lb = fma(ex, ex, ey * ey);
+        mask |= lb <= best ? 1ull << b : 0ull;
+    }
+    while (__ballot(mask != 0ull) != 0ull) {             // (3) uniform loop, per-lane blocks
+        const bool on = mask != 0ull;
+        const int b = on ? (int)__builtin_ctzll(mask) : 0;
+        mask &= mask - 1ull;
+#pragma unroll
+        for (int j = 1; j < NEAR_BLK; j++) {             // the head (j = 0) has been looked at
+            const int i = b * NEAR_BLK + j;
+            const bool valid = on && i < nc;
+            const int ii = valid ? i : 0;
+            const double d = dist2(cl[ii], cl[S + ii], px, py);
+            const bool take = valid && (d < best || (d == best && i < idx));
+            best = take ? d : best;
+            idx = take ? i : idx;
+        }
     }
     return idx;
 }

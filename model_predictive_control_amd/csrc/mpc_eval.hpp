@@ -220,6 +220,13 @@ rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 // per (slot, stage) record written for gradient requests: dL/dx (NX), dL/du (2), T (NX x NX)
 template <int MODEL> struct JacRec { static constexpr int SIZE = ModelDim<MODEL>::NX * (ModelDim<MODEL>::NX + 1) + 2; };
 
+// block boxes of centerline row `row` (null when none were prepared: full scan)
+__device__ __forceinline__ const double *box_row(const DevCfg &c, const Workspace &w, int row)
+{
+    const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
+    return w.cl_boxes ? w.cl_boxes + (size_t)row * NB * 4 : nullptr;
+}
+
 // K1b for one (request, stage): nearest point, stage cost, ALM terms and -- for gradient requests --
 // the stage's cost gradient and transition sensitivities.  `put(f, v)` stores field f of the stage
 // record: dL/dx (NX), dL/du (2), T (NX x NX), and field JS = the stage cost.  One body for the
@@ -230,10 +237,11 @@ template <int MODEL, class Put>
 __device__ __forceinline__ void stage_record(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
                                              int k, const double (&xs)[ModelDim<MODEL>::NX],
                                              const double (&xe)[ModelDim<MODEL>::NX], double d, double dl,
-                                             const double *__restrict__ clp, Put put)
+                                             const double *__restrict__ clp, const double *__restrict__ bxp, Put put)
 {
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
-    const int idx = nearest_index(c, clp, xe[0], xe[1]);
+    // bxp: the block boxes of this centerline row (null: look at every point) -- same index either way
+    const int idx = bxp ? nearest_index_blocks(c, clp, bxp, xe[0], xe[1]) : nearest_index(c, clp, xe[0], xe[1]);
     Geom g;
     load_geom(c, clp, idx, g);
     double xb[NX], ub[2] = {0.0, 0.0};
@@ -347,7 +355,7 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
     const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
     double *const jr = w.jac + (size_t)k * JS * St + uslot;
     double *const sl = w.stage_L + (size_t)k * St + uslot;
-    stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp,
+    stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, box_row(c, w, SHARED_CL ? 0 : w.cl_index[a]),
                         [=](int f, double v) { if (f == JS) *sl = v; else jr[(size_t)f * St] = v; });
 }
 
@@ -407,7 +415,8 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
             const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
             const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
             double *const r = s_rec + k * SPB + j;
-            stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, [=](int f, double v) { r[(size_t)f * NS] = v; });
+            stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, box_row(c, w, SHARED_CL ? 0 : w.cl_index[a]),
+                                [=](int f, double v) { r[(size_t)f * NS] = v; });
         }
     }
     __syncthreads();

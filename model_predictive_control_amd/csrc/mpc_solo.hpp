@@ -70,7 +70,8 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
         for (int i = 0; i < NX; i++) { xs[i] = traj[lane * NX + i]; xe[i] = traj[(lane + 1) * NX + i]; }
         const double *__restrict__ clp = w.cl_index ? w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S : w.cl;
         double *const r = rec + lane;
-        stage_record<MODEL>(c, w, a, ch2, is_g, lane, xs, xe, d, dl, clp, [=](int f, double v) { r[f * N] = v; });
+        stage_record<MODEL>(c, w, a, ch2, is_g, lane, xs, xe, d, dl, clp, box_row(c, w, w.cl_index ? w.cl_index[a] : 0),
+                            [=](int f, double v) { r[f * N] = v; });
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rec[f * N + k]; });

@@ -59,6 +59,7 @@ struct Workspace {
     int *agent_of;                                 // [St]           agent of a slot (-1: none)
     const double *cl;                              // [C][2S]
     const int *cl_index;                           // [B] or null
+    const double *cl_boxes;                        // [C][NB][4] block bounding boxes of the centerline rows, or null
     double *psi_direct;                            // direct-mode K1 output (standalone evaluation)
     double *ws_xe, *ws_ge, *ws_yhe, *ws_Sig;       // the workspace's own rows (xe/ge/yhe/Sig may alias caller buffers)
     int B, Bp;                                     // agents of this view, rounded up to 64

@@ -26,12 +26,13 @@ def gather_controls(local, B_total, dst=0, group=None):
     bmax = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros(bmax, k, dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    # all_gather keeps one code path for gloo and RCCL (gather is not implemented by every
-    # backend build); the payload is tiny next to a solve (21 MB/rank at B = 524288, N = 20)
     if dist.get_backend(group) == "gloo" and pad.is_cuda:
         pad = pad.cpu()   # rehearsal on one GPU box: gloo moves host tensors
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
+    # a gather to `dst` ("no collective beyond a final gather"): every rank sends its shard
+    # once, only `dst` receives -- 1/world of the bytes an all_gather would move over xGMI
+    dst_global = dst if group is None else dist.get_global_rank(group, dst)
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, gather_list=bufs, dst=dst_global, group=group)
     if rank != dst:
         return None
     return torch.cat([bufs[r][:hi - lo] for r, (lo, hi) in enumerate(sizes)], 0).to(local.device)

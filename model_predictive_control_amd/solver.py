@@ -38,6 +38,8 @@ class BatchedMPC:
         h = C.c_void_p()
         _lib.check(self.lib.mpc_create(C.byref(cfg), idx, C.byref(h)))
         self._h = h
+        import os
+        self._nearest_blocks = "MPC_NEAREST_BLOCKS" in os.environ
 
     def close(self):
         if getattr(self, "_h", None):
@@ -78,6 +80,10 @@ class BatchedMPC:
             self._chk(cl_index, (B,), "cl_index", torch.int32)
             if B and (int(cl_index.min()) < 0 or int(cl_index.max()) >= cl.shape[0]):
                 raise ValueError("cl_index out of range")
+        if self._nearest_blocks:
+            # f-2: block boxes of this table for the pruned nearest-point search (a few threads; redone
+            # on every call because the caller may have changed the table in place)
+            _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
         return cl
 
     def _empty(self, *shape, dtype=torch.float64):
@@ -235,6 +241,11 @@ class BatchedMPC:
     def set_groups(self, groups):
         """Sub-batch pipelining over HIP streams (0 = automatic)."""
         _lib.check(self.lib.mpc_set_groups(self._h, int(groups)))
+
+    def set_nearest_blocks(self, on=True):
+        """Block-pruned nearest-point search or (default) the full 98-candidate scan: same index."""
+        self._nearest_blocks = bool(on)
+        _lib.check(self.lib.mpc_set_nearest_blocks(self._h, int(bool(on))))
 
     def set_solo_max(self, max_requests):
         """Requests per round up to which a group finishes in the persistent wave-per-agent kernel (0 = off)."""

@@ -35,6 +35,43 @@ def _worker(rank, world, port, B, k, out_dir):
     dist.destroy_process_group()
 
 
+def _shard_worker(rank, world, port, B, out_dir):
+    """What every rank of bench.py does before its solve: take its contiguous shard of the GLOBAL
+    synthetic batch.  The rows must be the ones a single process generates for those agent indices, so
+    that every sharding of the batch solves the same problems (and the per-N checksums are comparable)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_states", os.path.join(ROOT, "bench.py"))
+    from model_predictive_control_amd.sharding import gather_controls, shard_bounds
+    # bench.py imports the HIP package at module level; only its pure-NumPy generator is used here
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    lo, hi = shard_bounds(B, rank, world)
+    for model in (0, 1):
+        local = torch.from_numpy(bench.synthetic_states(model, lo, hi))
+        full = gather_controls(local, B, dst=0)
+        if rank == 0:
+            np.save(os.path.join(out_dir, f"states{model}.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shards_are_the_rows_of_the_single_process_batch(tmp_path):
+    B, world = 10000, 2          # crosses the generator's 4096-agent blocks at a ragged boundary
+    port = _free_port()
+    mp.spawn(_shard_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_states", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    for model, nx in ((0, 4), (1, 6)):
+        got = np.load(os.path.join(str(tmp_path), f"states{model}.npy"))
+        ref = bench.synthetic_states(model, 0, B)
+        assert got.shape == (B, nx) and np.array_equal(got, ref)
+        # and a shard taken on its own equals the same slice (pure function of the global index)
+        assert np.array_equal(bench.synthetic_states(model, 4000, 4200), ref[4000:4200])
+
+
 def _run(B, k, tmp_path, world=2):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, B, k, str(tmp_path)), nprocs=world, join=True)
