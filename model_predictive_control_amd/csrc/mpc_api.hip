@@ -44,7 +44,10 @@ struct mpc_handle {
     bool nearest_blocks = false;          // MPC_NEAREST_BLOCKS / mpc_set_nearest_blocks: the pruned search (same
                                           // index; measured slower than the full scan: profiles/r02_nearest_blocks.txt)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
-                                // wave-per-agent kernel (MPC_SOLO_MAX; 0 = rounds only)
+                                // wave-per-agent kernel (MPC_SOLO_MAX / mpc_set_solo_max; 0 = rounds only).
+                                // Default: 1024 for the kinematic model up to N = 32; 0 otherwise (measured:
+                                // the Pacejka rollout is one serial chain whichever kernel runs it, and a wave
+                                // evaluates its agent's two requests of a round one after the other)
     int Bp_alloc = 0;      // workspace capacity (agents)
     char *arena = nullptr; // one device allocation carved into the Workspace arrays
     size_t arena_bytes = 0;
@@ -184,6 +187,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
+    h->solo_max = (cfg->model == MPC_MODEL_KINEMATIC && cfg->N <= 32) ? 1024 : 0;
     if (getenv("MPC_SOLO_MAX")) h->solo_max = atoi(getenv("MPC_SOLO_MAX"));
     h->nearest_blocks = getenv("MPC_NEAREST_BLOCKS") != nullptr;
     h->cfg = *cfg;
