@@ -187,7 +187,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
-    h->solo_max = (cfg->model == MPC_MODEL_KINEMATIC && cfg->N <= 32) ? 1024 : 0;
+    h->solo_max = cfg->N <= 32 ? 1024 : 0;
     if (getenv("MPC_SOLO_MAX")) h->solo_max = atoi(getenv("MPC_SOLO_MAX"));
     h->nearest_blocks = getenv("MPC_NEAREST_BLOCKS") != nullptr;
     h->cfg = *cfg;
@@ -482,10 +482,10 @@ static int eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *
     if (wave_path) {
         // one wave per agent, the evaluation as the persistent kernel runs it (mpc_solo.hpp)
         if (c.model == PAC) {
-            const size_t lds = sizeof(double) * solo_lds_doubles<PAC>(c.N, c.n, c.M, false);
+            const size_t lds = sizeof(double) * solo_lds_doubles<PAC>(c.nfe, c.N, c.n, c.M, false);
             hipLaunchKernelGGL(solo_eval_kernel<PAC>, dim3((unsigned)B), dim3(64), lds, s, c, h->ws, grad ? 1 : 0);
         } else {
-            const size_t lds = sizeof(double) * solo_lds_doubles<KIN>(c.N, c.n, c.M, false);
+            const size_t lds = sizeof(double) * solo_lds_doubles<KIN>(c.nfe, c.N, c.n, c.M, false);
             hipLaunchKernelGGL(solo_eval_kernel<KIN>, dim3((unsigned)B), dim3(64), lds, s, c, h->ws, grad ? 1 : 0);
         }
     } else
@@ -578,7 +578,7 @@ static void launch_solo_t(mpc_handle *h, const Workspace &v, hipStream_t s, int 
     int *list = listed ? v.lists : nullptr;   // the round lists are free once the group leaves the rounds
     if (listed)
         hipLaunchKernelGGL(solo_list_kernel, dim3((unsigned)((v.B + 255) / 256)), dim3(256), 0, s, v, list, ctr);
-    const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.N, c.n, c.M, MC < 0);
+    const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.nfe, c.N, c.n, c.M, MC < 0);
     int nblk = (bound + SOLO_WAVES - 1) / SOLO_WAVES;
     nblk = std::max(1, std::min(nblk, 4 * h->num_cus)); // one wave per SIMD is resident (registers); the rest queues
     hipLaunchKernelGGL((solo_kernel<MODEL, NE, MC>), dim3((unsigned)nblk), dim3(64 * SOLO_WAVES), lds, s, c, v, list,
@@ -605,7 +605,8 @@ static bool solo_fits(const mpc_handle *h)
 {
     const DevCfg &c = h->dc;
     const bool hist = c.n <= 64 && !h->step_regs && c.M * c.n <= 800;
-    const size_t per = c.model == PAC ? solo_lds_doubles<PAC>(c.N, c.n, c.M, hist) : solo_lds_doubles<KIN>(c.N, c.n, c.M, hist);
+    const size_t per = c.model == PAC ? solo_lds_doubles<PAC>(c.nfe, c.N, c.n, c.M, hist)
+                                      : solo_lds_doubles<KIN>(c.nfe, c.N, c.n, c.M, hist);
     return c.N <= 64 && per * SOLO_WAVES * sizeof(double) <= 64 * 1024;
 }
 

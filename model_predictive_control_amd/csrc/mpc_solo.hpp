@@ -15,8 +15,10 @@
 // thread-per-agent stage_forward on one lane otherwise; stage k of the horizon on lane k
 // (stage_record); the adjoint recursion on one lane (adjoint_rec) -- so an agent gets the
 // same bits whichever path serves it, and the host may switch on the live request counts.
-// Speculative gradients are not issued here (two evaluations of one agent run one after the other in
-// its wave, so a speculation can only lose); one that is pending when the agent arrives is consumed.
+// Speculative gradients: with the lane-serial rollout (Pacejka model) the speculative request of a
+// round is evaluated beside the regular one, on the other half of the wave (solo_dual); with the
+// wave-per-request rollout (kinematic model) two evaluations would run one after the other, so none is
+// issued -- one that is pending when the agent arrives is consumed either way.
 #pragma once
 #include "mpc_eval.hpp"
 
@@ -24,57 +26,69 @@ namespace mpc {
 
 constexpr int SOLO_WAVES = 1; // one wave per workgroup: nothing is shared between waves, and the dispatcher places them freely
 
-// doubles of LDS one wave needs: history copy (MC < 0), trajectory, stage records
-template <int MODEL> __host__ __device__ inline size_t solo_lds_doubles(int N, int n, int M, bool hist)
+// Two evaluations of one agent side by side in its wave (the request of the round on lanes 0 .. 31,
+// the speculative gradient on lanes 32 .. 63): possible when the rollout is the lane-serial one (the
+// wave-per-request kinematic rollout needs all 64 lanes) and a horizon fits half a wave.  With it the
+// persistent kernel keeps the round path's speculation for free: both serial chains advance in the same
+// instructions.
+__host__ __device__ inline bool solo_wide(int model, int nfe) { return model == KIN && nfe == 4; }
+__host__ __device__ inline bool solo_dual(int model, int nfe, int N) { return !solo_wide(model, nfe) && N <= 32; }
+
+// doubles of LDS one wave needs: history copy (MC < 0), trajectory, stage records (twice when dual)
+template <int MODEL> __host__ __device__ inline size_t solo_lds_doubles(int nfe, int N, int n, int M, bool hist)
 {
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
-    return (hist ? (size_t)2 * M * n : 0) + (size_t)(N + 1) * NX + (size_t)(JS + 1) * N;
+    const size_t per = (size_t)(N + 1) * NX + (size_t)(JS + 1) * N;
+    return (hist ? (size_t)2 * M * n : 0) + (solo_dual(MODEL, nfe, N) ? 2 : 1) * per;
 }
 
-// one evaluation (cost, or cost + gradient) of agent a's row `xrow` by the whole wave
+// the evaluation(s) agent `a` asked for (req: REQ_GRAD or REQ_COST, plus REQ_SPEC) by its whole wave
 template <int MODEL>
-__device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, int a, int lane, bool ch2,
-                                          bool is_g, double *traj, double *rec)
+__device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, int a, int lane, int req,
+                                          double *traj, double *rec)
 {
-    constexpr int NX = ModelDim<MODEL>::NX;
+    constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
     const int N = c.N, n = c.n;
+    const bool wide = solo_wide(MODEL, c.nfe), dual = solo_dual(MODEL, c.nfe, N);   // uniform
+    const int half = dual ? lane >> 5 : 0, hl = dual ? lane & 31 : lane;
+    const bool ch2 = half == 1;                                     // the speculative channel: xe2 -> ge2 only
+    const bool live = !ch2 || (req & REQ_SPEC) != 0;
+    const bool is_g = ch2 || (req & REQ_GRAD) != 0;
     const double *__restrict__ row = (ch2 ? w.xe2 : w.xe) + (size_t)a * n;
-    const bool stage_lane = lane < N;
-    const double d = stage_lane ? row[2 * lane] : 0.0, dl = stage_lane ? row[2 * lane + 1] : 0.0;
+    const bool stage_lane = live && hl < N;
+    const double d = stage_lane ? row[2 * hl] : 0.0, dl = stage_lane ? row[2 * hl + 1] : 0.0;
+    double *const tj = traj + (size_t)half * ((size_t)(N + 1) * NX);
+    double *const rc = rec + (size_t)half * ((size_t)(JS + 1) * N);
     double x0[NX];
 #pragma unroll
     for (int i = 0; i < NX; i++) x0[i] = w.x0[(size_t)a * NX + i];
-    bool wide = false;
     if constexpr (MODEL == KIN) {
-        if (c.nfe == 4) {                                  // uniform
-            wide = true;
-            kin_wide_rollout(c, row, x0, d, dl, lane, [=](int k, int i, double v) { traj[k * 4 + i] = v; });
-        }
+        if (wide) kin_wide_rollout(c, row, x0, d, dl, lane, [=](int k, int i, double v) { tj[k * 4 + i] = v; });
     }
-    if (!wide && lane == 0) {                              // the serial recurrence, as rollout_kernel runs it
+    if (!wide && hl == 0 && live) {                        // the serial recurrence, as rollout_kernel runs it
         double x[NX];
 #pragma unroll
-        for (int i = 0; i < NX; i++) { x[i] = x0[i]; traj[i] = x0[i]; }
+        for (int i = 0; i < NX; i++) { x[i] = x0[i]; tj[i] = x0[i]; }
         for (int k = 0; k < N; k++) {
             StageInput<MODEL> u;
             prep_input(c, row[2 * k], row[2 * k + 1], u);
             stage_forward<MODEL>(c, u, x);
 #pragma unroll
-            for (int i = 0; i < NX; i++) traj[(k + 1) * NX + i] = x[i];
+            for (int i = 0; i < NX; i++) tj[(k + 1) * NX + i] = x[i];
         }
     }
     __builtin_amdgcn_wave_barrier();                       // LDS is in order within a wave
     if (stage_lane) {
         double xs[NX], xe[NX];
 #pragma unroll
-        for (int i = 0; i < NX; i++) { xs[i] = traj[lane * NX + i]; xe[i] = traj[(lane + 1) * NX + i]; }
+        for (int i = 0; i < NX; i++) { xs[i] = tj[hl * NX + i]; xe[i] = tj[(hl + 1) * NX + i]; }
         const double *__restrict__ clp = w.cl_index ? w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S : w.cl;
-        double *const r = rec + lane;
-        stage_record<MODEL>(c, w, a, ch2, is_g, lane, xs, xe, d, dl, clp, box_row(c, w, w.cl_index ? w.cl_index[a] : 0),
+        double *const r = rc + hl;
+        stage_record<MODEL>(c, w, a, ch2, is_g, hl, xs, xe, d, dl, clp, box_row(c, w, w.cl_index ? w.cl_index[a] : 0),
                             [=](int f, double v) { r[f * N] = v; });
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rec[f * N + k]; });
+    if (hl == 0 && live) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rc[f * N + k]; });
 }
 
 // list of the agents of this view that are still running (phase != PH_DONE), in agent order inside a
@@ -98,7 +112,7 @@ __global__ void __launch_bounds__(64, 1) solo_eval_kernel(const DevCfg c, const 
     extern __shared__ double s_solo[];
     double *traj = s_solo;
     double *rec = traj + (size_t)(c.N + 1) * ModelDim<MODEL>::NX;
-    solo_eval<MODEL>(c, w, blockIdx.x, threadIdx.x, false, want_grad != 0, traj, rec);
+    solo_eval<MODEL>(c, w, blockIdx.x, threadIdx.x, want_grad ? REQ_GRAD : REQ_COST, traj, rec);
 }
 
 // ctr[0] = claim counter, ctr[1] = number of list entries (list == nullptr: every agent of the view)
@@ -109,7 +123,8 @@ solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int
 {
     extern __shared__ double s_solo[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t per_wave = solo_lds_doubles<MODEL>(c.N, c.n, c.M, MC < 0);
+    const size_t per_wave = solo_lds_doubles<MODEL>(c.nfe, c.N, c.n, c.M, MC < 0);
+    const bool spec = solo_dual(MODEL, c.nfe, c.N);      // speculative gradients only where they ride along
     double *hist = s_solo + (size_t)wv * per_wave;
     double *traj = hist + (MC < 0 ? (size_t)2 * c.M * c.n : 0);
     double *rec = traj + (size_t)(c.N + 1) * ModelDim<MODEL>::NX;
@@ -122,9 +137,9 @@ solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int
         const int a = list ? list[i] : i;
         for (long long trip = 0; trip < max_trips; trip++) {
             const AgentIn<NE> in = load_agent<NE>(c, w, a, lane);
-            const int req = advance_agent<NE, MC>(c, w, a, lane, in, hist, false, /*allow_spec=*/false);
+            const int req = advance_agent<NE, MC>(c, w, a, lane, in, hist, false, /*allow_spec=*/spec);
             if ((req & (REQ_GRAD | REQ_COST)) == 0) break;              // uniform: the agent is done
-            solo_eval<MODEL>(c, w, a, lane, false, (req & REQ_GRAD) != 0, traj, rec);
+            solo_eval<MODEL>(c, w, a, lane, req, traj, rec);
         }
     }
 }

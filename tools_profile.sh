@@ -1,29 +1,30 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun): kernel-trace stats and, in separate passes,
-# the HBM traffic counters.  Outputs land in gpurun_out/<tag>/ ; summaries are copied to profiles/.
+# Profiling recipe (run on the GPU box through gpurun):   bash tools_profile.sh r02a
+#   1. rocprofv3 --kernel-trace --stats of bench.py            -> kernel_stats.csv
+#   2. separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes     -> pmc_raw.json  (HBM traffic per kernel)
+#   3. SQ counters with one sub-batch group (no overlap)       -> sq_counters.txt
+#   4. kernel trace of one solve, one group, persistent kernel on / off -> tail.txt
+# Outputs land in gpurun_out/<tag>/ ; tools_pmc_summary.py copies the summaries to profiles/<tag>_*.
+# (counter passes never combine --pmc with the hip/hsa trace domains: kernel-trace only)
 set -e
 TAG=${1:-prof}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+B="--no-cpu-baseline --no-kernel-pass"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+echo stats done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 $B > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo fetch done
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 $B > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+echo write done
+export MPC_GROUPS=1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 1 --warmup 0 $B > $OUT/bench_sq.json 2> $OUT/sq.err || true
+echo sq done
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_solo -- python3 $R/bench.py --steps 1 --warmup 1 $B > $OUT/bench_trace_solo.json 2> $OUT/trace_solo.err
+MPC_SOLO_MAX=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_rounds -- python3 $R/bench.py --steps 1 --warmup 1 $B > $OUT/bench_trace_rounds.json 2> $OUT/trace_rounds.err
+unset MPC_GROUPS
+echo trace done
 cd $R
-python3 - <<PY
-import csv, glob, json, collections
-out = {}
-for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
-    acc = collections.defaultdict(lambda: [0.0, 0])
-    for f in files:
-        for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == key:
-                k = row["Kernel_Name"].split("(")[0]
-                acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
-    out[key] = {k: {"sum": v[0], "dispatches": v[1]} for k, v in acc.items()}
-json.dump(out, open("$OUT/pmc_raw.json", "w"), indent=1)
-print(json.dumps({k: {kk: vv for kk, vv in v.items() if "mpc" in kk} for k, v in out.items()}, indent=1)[:3000])
-PY
-find $OUT -name "*kernel_stats.csv" | head -2
+python3 tools_pmc_summary.py $TAG
