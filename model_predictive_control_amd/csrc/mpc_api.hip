@@ -34,6 +34,7 @@ struct mpc_handle {
     int apb_env = 0;            // MPC_APB: agents per step-kernel workgroup (4, 16, 64; 0 = by batch size)
     bool fused_eval = true;     // K1b + K1c in one launch (MPC_UNFUSED_EVAL: the two-kernel path)
     int fused_max = 16384;      // ... while a round holds at most this many requests (MPC_FUSED_MAX)
+    bool quad_rollout = true;   // K1a by two (kinematic) / four (Pacejka) lanes per request (MPC_NO_QUAD: one thread)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
     int num_cus = 256;
     // block bounding boxes of the centerline table last handed to mpc_centerline_blocks
@@ -183,6 +184,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (device < 0 || device >= ndev) return fail(MPC_E_ARG, "mpc_create: no such device");
     mpc_handle *h = new mpc_handle();
     h->step_regs = getenv("MPC_STEP_REGS") != nullptr;
+    h->quad_rollout = getenv("MPC_NO_QUAD") == nullptr;
     if (getenv("MPC_WIDE_MAX")) h->wide_max = atoi(getenv("MPC_WIDE_MAX"));
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
@@ -301,7 +303,21 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         if (wide)
             hipLaunchKernelGGL(rollout_wide_kernel, dim3((unsigned)(nblk * 16)), dim3(256), 0, s, c, w, lists, counts);
     }
-    if (!wide)
+    bool quad = false;
+    if constexpr (MODEL == KIN) {
+        // two lanes per request (rollout_pair_kernel); the wave-per-request kernel keeps the rounds with few requests
+        quad = !wide && h->quad_rollout && c.nfe == 4;
+        if (quad)
+            hipLaunchKernelGGL(rollout_pair_kernel, dim3((unsigned)(nblk * 2)), dim3(64),
+                               sizeof(double) * 32 * (size_t)(c.n + 1), s, c, w, lists, counts, nG, nC);
+    }
+    if constexpr (MODEL == PAC) {
+        quad = h->quad_rollout;
+        if (quad)
+            hipLaunchKernelGGL(rollout_quad_kernel, dim3((unsigned)(nblk * 4)), dim3(64),
+                               sizeof(double) * 16 * (size_t)(c.n + 1), s, c, w, lists, counts, nG, nC);
+    }
+    if (!wide && !quad)
         hipLaunchKernelGGL((rollout_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), lds, s, c, w, lists, counts, nG, nC);
     if (eva) (void)hipEventRecord(eva, s);
     // (kinematic model only: the Pacejka stage needs more registers than the fused kernel leaves it)

@@ -213,27 +213,38 @@ MPC_DEV void prep_input(const DevCfg &c, double d, double dl, StageInput<KIN> &s
 #pragma clang fp contract(off)   // fixed roundings: the same bits in every kernel this is inlined into
     clip_input(c, d, dl, s.mk0, s.mk1);
     const double L = c.lf + c.lr;
-    // Steering angles live inside the box (|delta| <= 0.32 by default): tan from the reduced sin/cos
-    // kernels, and sin/cos(beta) straight from the triangle (t, L) instead of through the angle.
-    // One wave-uniform test guards the whole fast path; a lane outside it takes the library route,
-    // whatever its neighbours do.
+    // tan(delta) from sin/cos, and sin/cos(beta) straight from the triangle (t, L) instead of through
+    // the angle.  Three tiers, each guarded by a wave-uniform test so that the common case is one
+    // straight-line block: steering angles inside the box (|delta| <= 0.32 by default) take the reduced
+    // minimax kernels as they are; anything finite takes the same kernels behind the Cody-Waite
+    // reduction -- line-search trial points leave the box, and a wave that paid the library route for
+    // one such lane (~1000 instructions per stage) held back its whole launch (profiles/r02a trace:
+    // K1a 82 us on first-round data, 140 - 247 us in mid-solve); only non-finite or huge angles go to
+    // the library.  What a lane computes does not depend on its neighbours.
     const bool ok = fabs(dl) <= 0.75 && L > 0.0;
-    const SinCos sd = kernel_sincos(ok ? dl : 0.0);
+    SinCos sd = kernel_sincos(ok ? dl : 0.0);
+    bool mid = false;
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) {
+        mid = !ok && fabs(dl) < 1.0e5 && L > 0.0;
+        const SinCos sr = lean_sincos(mid ? dl : 0.0);
+        sd.s = mid ? sr.s : sd.s; sd.c = mid ? sr.c : sd.c;
+    }
+    const bool fast = ok || mid;
     double td = sd.s / sd.c;
     double t = c.lf * td;
     const double hyp2 = t * t + L * L;
     const double rh = 1.0 / sqrt(hyp2);
     double sb = t * rh, cb = L * rh;
     double beta;
-    if (__builtin_expect(__ballot(!ok) == 0ull, 1)) beta = lean_atan2(t, L);
+    if (__builtin_expect(__ballot(!fast) == 0ull, 1)) beta = lean_atan2(t, L);
     else {
         const double td_s = m_tan(dl), t_s = c.lf * td_s;
         const double beta_s = m_atan2(t_s, L);
         const SinCos scb = m_sincos(beta_s);
-        const double beta_f = lean_atan2(ok ? t : 0.0, ok ? L : 1.0);
-        beta = ok ? beta_f : beta_s;
-        td = ok ? td : td_s; t = ok ? t : t_s;
-        sb = ok ? sb : scb.s; cb = ok ? cb : scb.c;
+        const double beta_f = lean_atan2(fast ? t : 0.0, fast ? L : 1.0);
+        beta = fast ? beta_f : beta_s;
+        td = fast ? td : td_s; t = fast ? t : t_s;
+        sb = fast ? sb : scb.s; cb = fast ? cb : scb.c;
     }
     s.beta = beta;
     s.sb_lr = sb / c.lr;
@@ -347,6 +358,24 @@ MPC_DEV void vjp(const DevCfg &c, const StageInput<KIN> &u, const Lin<KIN> &l, c
 
 MPC_DEV double sign_of(double v) { return (v > 0.0 ? 1.0 : 0.0) - (v < 0.0 ? 1.0 : 0.0); }
 
+// car_dynamics.py:121-129 from the heading's and the two axles' sines/cosines: drivetrain force, lateral
+// forces, the six derivatives.  Fixed roundings: the thread-per-request RHS and the four-lane RHS
+// (rhs_quad) must agree bit for bit.
+MPC_DEV void pac_assemble(const DevCfg &c, const StageInput<PAC> &u, double vx, double vy, double om, double sp,
+                          double cp, double stf, double str, double (&k)[6])
+{
+#pragma clang fp contract(off)
+    const double frx = (c.cm1 - c.cm2 * vx) * u.d - c.cr0 * sign_of(vx) - c.cr2 * vx * vx;
+    const double ffy = c.df * stf;
+    const double fry = c.dr * str;
+    k[0] = vx * cp - vy * sp;
+    k[1] = vx * sp + vy * cp;
+    k[2] = om;
+    k[3] = (frx - ffy * u.sd + c.mass * vy * om) * c.inv_mass;
+    k[4] = (fry + ffy * u.cd - c.mass * vx * om) * c.inv_mass;
+    k[5] = (ffy * c.lf * u.cd - fry * c.lr) * c.inv_iz;
+}
+
 // Pacejka bicycle, car_dynamics.py:115-129.  x = [x, y, phi, vx, vy, omega]
 template <bool LIN>
 MPC_DEV void rhs(const DevCfg &c, const StageInput<PAC> &u, const double (&x)[6], double (&k)[6],
@@ -379,15 +408,8 @@ MPC_DEV void rhs(const DevCfg &c, const StageInput<PAC> &u, const double (&x)[6]
         const SinCos a = m_sincos(c.cf * m_atan(c.bf * af)), b = m_sincos(c.cr * m_atan(c.br * ar));
         stf = a.s; ctf = a.c; str = b.s; ctr = b.c;
     }
-    const double frx = (c.cm1 - c.cm2 * vx) * u.d - c.cr0 * sign_of(vx) - c.cr2 * vx * vx;
     const double ffy = c.df * stf;
-    const double fry = c.dr * str;
-    k[0] = vx * cp - vy * sp;
-    k[1] = vx * sp + vy * cp;
-    k[2] = om;
-    k[3] = (frx - ffy * u.sd + c.mass * vy * om) * c.inv_mass;
-    k[4] = (fry + ffy * u.cd - c.mass * vx * om) * c.inv_mass;
-    k[5] = (ffy * c.lf * u.cd - fry * c.lr) * c.inv_iz;
+    pac_assemble(c, u, vx, vy, om, sp, cp, stf, str, k);
     if (LIN) {
         lin.sp = sp; lin.cp = cp; lin.f0 = k[0]; lin.f1 = k[1];
         lin.vx = vx; lin.vy = vy; lin.om = om;
@@ -423,6 +445,45 @@ MPC_DEV void vjp(const DevCfg &c, const StageInput<PAC> &u, const Lin<PAC> &l, c
     ub[1] += dl_b * u.mk1;
 }
 
+// The Pacejka RHS by FOUR lanes (a DPP quad) that all hold the same state and input.  Its cost is
+// three chains of transcendentals -- the heading's sin/cos, and per axle atan2 -> atan -> sin/cos -- and
+// a lone wave issues them one after the other (340 dependent-ish fp64 instructions per evaluation, 16 N
+// evaluations per rollout: the latency that bounds a Pacejka solve's tail).  Here lane role 1 walks the
+// front axle's chain, role 2 (and 3) the rear axle's, role 0 the heading's -- ONE instruction stream:
+// the roles differ only in the operands they select -- the three results are exchanged by quad
+// broadcasts, and every lane assembles the derivatives, so all four keep identical copies of the
+// state.  Same operations on the same values as rhs<false>: bit-identical.
+template <int CTRL> MPC_DEV double quad_bcast(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+MPC_DEV void rhs_quad(const DevCfg &c, const StageInput<PAC> &u, const double (&x)[6], double (&k)[6], int role)
+{
+    const double vx = x[3], vy = x[4], om = x[5];
+    const double a1 = om * c.lf + vy;
+    const double a2 = om * c.lr - vy;
+    const double fa1 = fabs(a1), fa2 = fabs(a2), fvx = fabs(vx);
+    const bool ok = fabs(x[2]) < 1.0e5 && fa1 < 1.0e300 && fa2 < 1.0e300 && fvx < 1.0e300 &&
+                    (fvx != 0.0 || (fa1 != 0.0 && fa2 != 0.0)) && fabs(u.dl) < 1.0e5 &&
+                    fabs(c.cf) < 6.0e4 && fabs(c.cr) < 6.0e4;
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) {      // some lane is out of the fast ranges: every
+        Lin<PAC> dummy;                                     // lane evaluates the whole RHS by itself
+        rhs<false>(c, u, x, k, dummy);
+        return;
+    }
+    const bool front = role == 1;
+    const double t = lean_atan2(front ? a1 : a2, vx);
+    const double al = front ? u.dl - t : t;                 // alpha_f = delta - atan2(a1, vx); alpha_r = atan2(a2, vx)
+    const double axle = (front ? c.cf : c.cr) * m_atan((front ? c.bf : c.br) * al);
+    const SinCos sc = lean_sincos(role == 0 ? x[2] : axle);
+    const double sp = quad_bcast<0x00>(sc.s), cp = quad_bcast<0x00>(sc.c);
+    const double stf = quad_bcast<0x55>(sc.s), str = quad_bcast<0xAA>(sc.s);
+    pac_assemble(c, u, vx, vy, om, sp, cp, stf, str, k);
+}
+
 // ---------------------------------------------------------------------------------- RK4
 template <int MODEL> struct ModelDim { static constexpr int NX = MODEL == PAC ? 6 : 4; };
 
@@ -441,34 +502,40 @@ MPC_DEV void rk_rhs(const DevCfg &c, const StageInput<PAC> &u, const StepTrig &,
 }
 MPC_DEV void step_trig(const DevCfg &, const StageInput<PAC> &, const double (&)[6], StepTrig &) {}
 
-// one classical RK4 step (car_dynamics.py:136-145, h = Ts / nfe, input held)
-template <int MODEL>
-MPC_DEV void rk4_step(const DevCfg &c, const StageInput<MODEL> &u, double (&x)[ModelDim<MODEL>::NX])
+// one classical RK4 step (car_dynamics.py:136-145, h = Ts / nfe, input held) of the Pacejka model around
+// an RHS evaluator f(x, k) -- the thread-per-request one or the four-lane one.  Fixed roundings: the
+// two must produce the same bits.
+template <class F>
+MPC_DEV void rk4_step_pac(const DevCfg &c, double (&x)[6], F f)
 {
-    constexpr int NX = ModelDim<MODEL>::NX;
-    const double h = c.h;
-    double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
-    Lin<MODEL> dummy;
-    StepTrig tr;
-    step_trig(c, u, x, tr);
-    rk_rhs<false, 0>(c, u, tr, x, k1, dummy);
+#pragma clang fp contract(off)
+    const double h = c.h, hh = 0.5 * h, h6 = h / 6.0;
+    double k1[6], k2[6], k3[6], k4[6], t[6];
+    f(x, k1);
 #pragma unroll
-    for (int i = 0; i < NX; i++) t[i] = x[i] + 0.5 * h * k1[i];
-    rk_rhs<false, 1>(c, u, tr, t, k2, dummy);
+    for (int i = 0; i < 6; i++) t[i] = fma(hh, k1[i], x[i]);
+    f(t, k2);
 #pragma unroll
-    for (int i = 0; i < NX; i++) t[i] = x[i] + 0.5 * h * k2[i];
-    rk_rhs<false, 2>(c, u, tr, t, k3, dummy);
+    for (int i = 0; i < 6; i++) t[i] = fma(hh, k2[i], x[i]);
+    f(t, k3);
 #pragma unroll
-    for (int i = 0; i < NX; i++) t[i] = x[i] + h * k3[i];
-    rk_rhs<false, 3>(c, u, tr, t, k4, dummy);
+    for (int i = 0; i < 6; i++) t[i] = fma(h, k3[i], x[i]);
+    f(t, k4);
 #pragma unroll
-    for (int i = 0; i < NX; i++) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    for (int i = 0; i < 6; i++) x[i] = fma(h6, ((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i], x[i]);
 }
 
 // one stage x <- f_d(x, u) : nfe RK4 steps
 MPC_DEV void stage_forward_steps(const DevCfg &c, const StageInput<PAC> &u, double (&x)[6])
 {
-    for (int s = 0; s < c.nfe; s++) rk4_step<PAC>(c, u, x);
+    for (int s = 0; s < c.nfe; s++)
+        rk4_step_pac(c, x, [&](const double (&y)[6], double (&k)[6]) { Lin<PAC> dummy; rhs<false>(c, u, y, k, dummy); });
+}
+// the same by a quad of lanes holding identical (x, u); role = lane & 3 (see rhs_quad)
+MPC_DEV void stage_forward_quad(const DevCfg &c, const StageInput<PAC> &u, double (&x)[6], int role)
+{
+    for (int s = 0; s < c.nfe; s++)
+        rk4_step_pac(c, x, [&](const double (&y)[6], double (&k)[6]) { rhs_quad(c, u, y, k, role); });
 }
 MPC_DEV void stage_forward_steps(const DevCfg &c, const StageInput<KIN> &u, double (&x)[4])
 {

@@ -92,6 +92,139 @@ rollout_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
     }
 }
 
+// K1a of the kinematic model (nfe = 4) by TWO lanes per request: both walk the cheap heading/speed
+// recursion of a stage (4 x 17 dependent fma), lane 0 evaluates the position increments -- where the
+// sin/cos are -- of RK4 steps 0 and 1, lane 1 those of steps 2 and 3; they swap them and both add the
+// four in step order, so the pair keeps identical copies of the state.  Twice the waves at ~0.57 of
+// the chain length: a round with all agents active gives the thread-per-request kernel 1.4 waves per
+// SIMD (its makespan is that of the SIMDs holding two), a sub-batch group a third of that.  The same
+// helper functions with fixed roundings as rollout_kernel<KIN> and the wave-per-request kernel: same bits.
+__global__ void __launch_bounds__(64)
+rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
+                    const int *__restrict__ counts, int nG_imm, int nC_imm)
+{
+#pragma clang fp contract(off)
+    constexpr int RPB = 32;                              // requests per block
+    extern __shared__ double lds[];                      // [RPB][n + 1] control rows
+    const SlotMap sm(counts, nG_imm, nC_imm);
+    const int lane = threadIdx.x, q = lane >> 1, half = lane & 1;
+    const int uslot = blockIdx.x * RPB + q;
+    const int nslots = sm.nblk * 64;
+    const bool is_g = uslot < sm.gpad;
+    const int kslot = is_g ? uslot : uslot - sm.gpad;
+    const bool active = uslot < nslots && kslot < (is_g ? sm.nG : sm.nC);
+    const int *list = counts ? (is_g ? lists : lists + w.Ls) : nullptr;
+    const int raw = active ? (list ? list[kslot] : kslot) : -1;
+    const int n = c.n, N = c.N, ld = n + 1;
+    if (half == 0 && uslot < nslots) w.agent_of[uslot] = raw;
+    if (active) {
+        const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)(raw & AGENT_MASK) * n;
+        for (int j = half; j < n; j += 2) lds[q * ld + j] = row[j];
+    }
+    __builtin_amdgcn_wave_barrier();                     // one wave per workgroup: LDS is in order
+    if (!active) return;                                 // whole pairs leave together
+    const int a = raw & AGENT_MASK;
+    const size_t St = (size_t)w.St;
+    const double *urow = lds + q * ld;
+    double x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = w.x0[(size_t)a * 4 + i];
+    // lane `half` stores components 2 half and 2 half + 1 of every state
+    auto put = [&](int k) {
+        w.trajx[(size_t)(k * 4 + 2 * half) * St + uslot] = half ? x[2] : x[0];
+        w.trajx[(size_t)(k * 4 + 2 * half + 1) * St + uslot] = half ? x[3] : x[1];
+    };
+    put(0);
+    for (int k = 0; k < N; k++) {
+        const double d = urow[2 * k], dl = urow[2 * k + 1];
+        w.useq[(size_t)(2 * k + half) * St + uslot] = half ? dl : d;
+        StageInput<KIN> u;
+        prep_input(c, d, dl, u);
+        const bool ok = kin4_in_range(c, u, x);
+        if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
+            // heading / speed at the start of the four RK4 steps, and the stage values of each
+            double ph = x[2], v = x[3];
+            KinRK k0, k1, k2, k3;
+            const double ph0 = ph; kin_rk(c, u, v, k0); kin_next(c, k0, ph, v);
+            const double ph1 = ph; kin_rk(c, u, v, k1); kin_next(c, k1, ph, v);
+            const double ph2 = ph; kin_rk(c, u, v, k2); kin_next(c, k2, ph, v);
+            const double ph3 = ph; kin_rk(c, u, v, k3); kin_next(c, k3, ph, v);
+            // this lane's two increments: steps 2 half and 2 half + 1
+            KinRK ka, kb;
+            ka.v1 = half ? k2.v1 : k0.v1; ka.v2 = half ? k2.v2 : k0.v2; ka.v3 = half ? k2.v3 : k0.v3; ka.v4 = half ? k2.v4 : k0.v4;
+            ka.kp1 = half ? k2.kp1 : k0.kp1; ka.kp2 = half ? k2.kp2 : k0.kp2; ka.kp3 = half ? k2.kp3 : k0.kp3;
+            kb.v1 = half ? k3.v1 : k1.v1; kb.v2 = half ? k3.v2 : k1.v2; kb.v3 = half ? k3.v3 : k1.v3; kb.v4 = half ? k3.v4 : k1.v4;
+            kb.kp1 = half ? k3.kp1 : k1.kp1; kb.kp2 = half ? k3.kp2 : k1.kp2; kb.kp3 = half ? k3.kp3 : k1.kp3;
+            double dxa, dya, dxb, dyb;
+            kin_increment(c, u, half ? ph2 : ph0, ka, true, dxa, dya);
+            kin_increment(c, u, half ? ph3 : ph1, kb, true, dxb, dyb);
+            const double oxa = dpp_xchg<0xB1>(dxa), oya = dpp_xchg<0xB1>(dya);   // the partner's (quad_perm [1,0,3,2])
+            const double oxb = dpp_xchg<0xB1>(dxb), oyb = dpp_xchg<0xB1>(dyb);
+            double px = x[0], py = x[1];
+            px = px + (half ? oxa : dxa); py = py + (half ? oya : dya);           // step 0
+            px = px + (half ? oxb : dxb); py = py + (half ? oyb : dyb);           // step 1
+            px = px + (half ? dxa : oxa); py = py + (half ? dya : oya);           // step 2
+            px = px + (half ? dxb : oxb); py = py + (half ? dyb : oyb);           // step 3
+            x[0] = px; x[1] = py; x[2] = ph; x[3] = v;
+        } else {
+            stage_forward<KIN>(c, u, x);                 // some lane is out of range: the thread-per-request code
+        }
+        put(k + 1);
+    }
+}
+
+// K1a of the Pacejka model by FOUR lanes per request (rhs_quad): a workgroup of 64 threads takes 16
+// requests.  The rollout is one serial chain of 16 N RHS evaluations whatever the batch, and a batch of
+// 65 536 agents in three groups gives the thread-per-request kernel half a wave per SIMD: four times
+// the waves at 0.56 of the chain length fill the chip where it was idle, and shorten the chain where
+// a tail of few agents waits for it.  Same bits as rollout_kernel<PAC>.
+__global__ void __launch_bounds__(64)
+rollout_quad_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
+                    const int *__restrict__ counts, int nG_imm, int nC_imm)
+{
+    constexpr int NX = 6, RPB = 16;                      // requests per block
+    extern __shared__ double lds[];                      // [RPB][n + 1] control rows
+    const SlotMap sm(counts, nG_imm, nC_imm);
+    const int lane = threadIdx.x, q = lane >> 2, role = lane & 3;
+    const int uslot = blockIdx.x * RPB + q;
+    const int nslots = sm.nblk * 64;
+    const bool is_g = uslot < sm.gpad;
+    const int kslot = is_g ? uslot : uslot - sm.gpad;
+    const bool active = uslot < nslots && kslot < (is_g ? sm.nG : sm.nC);
+    const int *list = counts ? (is_g ? lists : lists + w.Ls) : nullptr;
+    const int raw = active ? (list ? list[kslot] : kslot) : -1;
+    const int n = c.n, N = c.N, ld = n + 1;
+    if (role == 0 && uslot < nslots) w.agent_of[uslot] = raw;
+    // stage in: the quad's own row, four elements per trip
+    if (active) {
+        const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)(raw & AGENT_MASK) * n;
+        for (int j = role; j < n; j += 4) lds[q * ld + j] = row[j];
+    }
+    __builtin_amdgcn_wave_barrier();                     // one wave per workgroup: LDS is in order
+    if (!active) return;                                 // whole quads leave together
+    const int a = raw & AGENT_MASK;
+    const size_t St = (size_t)w.St;
+    const double *urow = lds + q * ld;
+    double x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = w.x0[(size_t)a * NX + i];
+    // lane `role` stores components role and role + 4 of every state
+    auto put = [&](int k) {
+        w.trajx[(size_t)(k * NX + role) * St + uslot] = role == 0 ? x[0] : role == 1 ? x[1] : role == 2 ? x[2] : x[3];
+        if (role < 2) w.trajx[(size_t)(k * NX + 4 + role) * St + uslot] = role == 0 ? x[4] : x[5];
+    };
+    put(0);
+    for (int k = 0; k < N; k++) {
+        const double d = urow[2 * k], dl = urow[2 * k + 1];
+        if (role == 0) w.useq[(size_t)(2 * k) * St + uslot] = d;
+        if (role == 1) w.useq[(size_t)(2 * k + 1) * St + uslot] = dl;
+        StageInput<PAC> u;
+        prep_input(c, d, dl, u);
+        stage_forward_quad(c, u, x, role);
+        put(k + 1);
+    }
+}
+
 // K1a for few requests (late rounds, small batches): ONE WAVE per request instead of one thread.
 // The thread-per-agent rollout is a serial chain of 16 N sin/cos evaluations (~43 us whatever the
 // batch); here only the cheap linear heading/speed recursion stays serial (phase A), the 4 N position

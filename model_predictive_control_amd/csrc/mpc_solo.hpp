@@ -65,7 +65,22 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
     if constexpr (MODEL == KIN) {
         if (wide) kin_wide_rollout(c, row, x0, d, dl, lane, [=](int k, int i, double v) { tj[k * 4 + i] = v; });
     }
-    if (!wide && hl == 0 && live) {                        // the serial recurrence, as rollout_kernel runs it
+    if constexpr (MODEL == PAC) {
+        if (hl < 4 && live) {                              // the serial recurrence on a quad of lanes (rhs_quad)
+            double x[NX];
+#pragma unroll
+            for (int i = 0; i < NX; i++) { x[i] = x0[i]; if (hl == 0) tj[i] = x0[i]; }
+            for (int k = 0; k < N; k++) {
+                StageInput<PAC> u;
+                prep_input(c, row[2 * k], row[2 * k + 1], u);
+                stage_forward_quad(c, u, x, hl);
+                if (hl == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; i++) tj[(k + 1) * NX + i] = x[i];
+                }
+            }
+        }
+    } else if (!wide && hl == 0 && live) {                 // the serial recurrence, as rollout_kernel runs it
         double x[NX];
 #pragma unroll
         for (int i = 0; i < NX; i++) { x[i] = x0[i]; tj[i] = x0[i]; }

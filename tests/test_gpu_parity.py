@@ -487,6 +487,41 @@ def test_wide_rollout_is_bit_identical(dev, monkeypatch, N):
     assert (stw[:, 0] == 1).float().mean() >= (0.8 if N == 20 else 0.4)   # 300 iterations are short for N = 40
 
 
+@pytest.mark.parametrize("model,N", [(1, 12), (0, 20), (0, 40)])
+def test_quad_rollout_is_bit_identical(dev, monkeypatch, model, N):
+    """K1a splits a request over lanes: four for the Pacejka model (rollout_quad_kernel: the heading's and
+    the two axles' transcendental chains on different lanes of a DPP quad), two for the kinematic model
+    (rollout_pair_kernel: RK4 steps 0-1 / 2-3 of a stage).  Same operations on the same values as the
+    thread-per-request kernel: same cost and gradient, same solve; states outside the fast ranges
+    (vx = 0, huge heading, huge speed) included."""
+    monkeypatch.setenv("MPC_SOLO_MAX", "0")                     # K1a kernels, not the persistent kernel's rollout
+    monkeypatch.setenv("MPC_WIDE_MAX", "-1")
+    B = 333
+    x0 = synthetic_states(model, B, seed=23)
+    if model == 1:
+        x0[::29, 3] = 0.0; x0[::29, 4] = 0.0; x0[::29, 5] = 0.0     # atan2(0, 0): the library path, for the whole wave
+    else:
+        x0[::29, 3] = 60.0                                          # outside the rotation path's range
+    x0[5::31, 2] = 3.0e5                                        # heading beyond the lean range
+    rng = np.random.default_rng(3)
+    U = np.tile([0.6, 0.0], (B, N)) + rng.uniform(-.4, .4, (B, 2 * N)) * np.tile([1, .6], N)
+    X0, cl, Ut = T(x0, dev), T(straight_centerline(), dev), T(U, dev)
+    U0 = T(np.tile([1., 0.], (B, N)), dev)
+    cfg = mp.default_config(model, N, max_total_inner=300)
+    eq = mp.BatchedMPC(cfg, dev)
+    pq, gq, _ = eq.eval_cost_grad(X0, cl, Ut)
+    Uq, _, stq = eq.solve(X0, cl, U0)
+    monkeypatch.setenv("MPC_NO_QUAD", "1")
+    et = mp.BatchedMPC(cfg, dev)
+    monkeypatch.delenv("MPC_NO_QUAD")
+    pt, gt, _ = et.eval_cost_grad(X0, cl, Ut)
+    Ut_, _, stt = et.solve(X0, cl, U0)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1.25), torch.nan_to_num(b, nan=1.25))
+    assert same(pq, pt) and same(gq, gt) and same(Uq, Ut_) and same(stq, stt)
+    fin = torch.isfinite(pq)
+    assert fin.float().mean() >= 0.9 and (stq[:, 0] == 1).float().mean() >= (0.8 if N <= 20 else 0.3)
+
+
 @pytest.mark.parametrize("model,N,B,kw", [
     (0, 20, 700, {}), (1, 12, 300, {}), (0, 40, 150, {}), (0, 32, 100, dict(lbfgs_memory=25)),
     (1, 10, 96, dict(constr_mode=1, D_lb=[-np.inf] * 6, D_ub=[0.0] * 6, g_off=[20, 1, 1, 0.5, 1, 0.1], Sigma0=10.0)),
