@@ -213,6 +213,11 @@ def main():
         # (2) moved bytes: what the implementation sends through HBM per solve, from the committed PMC
         # passes (FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE), per launch x launches per solve
         pmc, pmc_src = pmc_profile()
+        workload = ("configs[1] shape at the metric's batch: %d agents/GPU, %s bicycle nx=%d nu=2, "
+                    "N=%d, box input constraints, straight S=100 centerline, ALM+PANOC eps=1e-6"
+                    % (args.batch, "Pacejka" if args.model else "kinematic", nx, N))
+        if pmc and pmc.get("workload") != workload:
+            pmc, pmc_src = None, None          # the committed counters describe another workload
         moved = None
         if pmc and pmc.get("hbm_bytes_per_solve"):
             mb = float(pmc["hbm_bytes_per_solve"])
@@ -271,9 +276,7 @@ def main():
             "value": B_total * K / dt, "unit": "solves/s", "n_gpus": world, "steps": K,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1] shape at the metric's batch: %d agents/GPU, %s bicycle nx=%d nu=2, "
-                                   "N=%d, box input constraints, straight S=100 centerline, ALM+PANOC eps=1e-6"
-                                   % (args.batch, "Pacejka" if args.model else "kinematic", nx, N),
+            "config": {"workload": workload,
                        "batch_per_gpu": args.batch, "horizon": N, "nx": nx, "nu": 2, "m_c": m,
                        "lbfgs_memory": int(cfg.lbfgs_memory), "tolerance": cfg.alm_eps,
                        "max_total_inner": int(cfg.max_total_inner), "max_total_evals": int(cfg.max_total_evals),

@@ -52,6 +52,10 @@ summary = {
     "correction": "gfx950: FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md HBM "
                   "section): read side doubled; other access widths uncalibrated",
 }
+try:
+    summary["workload"] = json.load(open(os.path.join(OUT, "bench_pmc_fetch.json")))["config"]["workload"]
+except Exception:
+    summary["workload"] = None
 total = total_unc = 0.0
 for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
     f, nf = acc["FETCH_SIZE"].get(k, [0.0, 0]); w, nw = acc["WRITE_SIZE"].get(k, [0.0, 0])
