@@ -34,6 +34,9 @@ struct mpc_handle {
     int apb_env = 0;            // MPC_APB: agents per step-kernel workgroup (4, 16, 64; 0 = by batch size)
     bool fused_eval = true;     // K1b + K1c in one launch (MPC_UNFUSED_EVAL: the two-kernel path)
     int fused_max = 16384;      // ... while a round holds at most this many requests (MPC_FUSED_MAX)
+    bool arrive_adjoint = false; // MPC_ARRIVE: K1c inside K1b's last-arriving stage block instead of a launch of its own
+                                 // (same bits; measured 3 % slower -- write-through record stores: DESIGN.md 6)
+    int *arrive_buf = nullptr;  // arrival counters, one per block of 64 slots
     bool quad_rollout = true;   // K1a by two (kinematic) / four (Pacejka) lanes per request (MPC_NO_QUAD: one thread)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
     int num_cus = 256;
@@ -185,6 +188,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     mpc_handle *h = new mpc_handle();
     h->step_regs = getenv("MPC_STEP_REGS") != nullptr;
     h->quad_rollout = getenv("MPC_NO_QUAD") == nullptr;
+    h->arrive_adjoint = getenv("MPC_ARRIVE") != nullptr;
     if (getenv("MPC_WIDE_MAX")) h->wide_max = atoi(getenv("MPC_WIDE_MAX"));
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
@@ -242,7 +246,8 @@ static int reserve(mpc_handle *h, int B)
     const size_t nd = 8 * n + 2 * M * n + 7 * m + REC;          // agent-major doubles per agent
     const size_t nscr = (N + 1) * nx + 2 * N + N + N * JS;       // K1 scratch doubles per slot
     const size_t ni = 4;                                         // list ints per agent
-    const size_t bytes = (nd * 8 + ni * 4) * (size_t)Bp + nscr * 8 * St + 4 * St + 8 * 4 * MPC_MAX_GROUPS + 256;
+    const size_t bytes = (nd * 8 + ni * 4) * (size_t)Bp + nscr * 8 * St + 4 * St + 8 * 4 * MPC_MAX_GROUPS + 256 +
+                         4 * (St / 64 + 16) + 256;
     char *base = nullptr;
     hipError_t e = hipMalloc((void **)&base, bytes);
     if (e != hipSuccess) return fail(MPC_E_ALLOC, "workspace hipMalloc failed: " + std::string(hipGetErrorString(e)));
@@ -265,6 +270,8 @@ static int reserve(mpc_handle *h, int B)
     w.counts = ip; // 8 ints per group
     w.totals = (unsigned long long *)(ip + 8 * MPC_MAX_GROUPS);
     w.solo_ctr = (int *)(w.totals + 8); // [group][claim counter, list length]
+    h->arrive_buf = w.solo_ctr + 2 * MPC_MAX_GROUPS + 32; // [St / 64 + 16]: stage blocks done per slot block
+    w.arrive = nullptr;
     w.Bp = Bp; w.B = B; w.St = (int)St; w.Ls = Bp;
     w.ws_xe = w.xe; w.ws_ge = w.ge; w.ws_yhe = w.yhe; w.ws_Sig = w.Sig;
     HIPCHK(hipMemset(base, 0, bytes));
@@ -339,6 +346,7 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
     else
         hipLaunchKernelGGL((stage_kernel<MODEL, false>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
     if (evb) (void)hipEventRecord(evb, s);
+    if (w.arrive) return true;               // K1c ran inside K1b (last-arriving stage block)
     hipLaunchKernelGGL((adjoint_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), 0, s, c, w, counts, nG, nC);
     return false;
 }
@@ -489,6 +497,8 @@ static int eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *
     // direct mode: the kernel reads and writes the caller's agent-major buffers in place
     Workspace w = h->ws;
     w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.cl_boxes = boxes_for(h, cl);
+    w.arrive = h->arrive_adjoint ? h->arrive_buf : nullptr;
+    if (w.arrive) HIPCHK(hipMemsetAsync(h->arrive_buf, 0, sizeof(int) * (size_t)(h->ws.St / 64 + 16), s));
     w.xe = const_cast<double *>(U); w.ge = grad ? grad : h->ws.ws_ge;
     w.y = const_cast<double *>(y); w.Sig = c.m ? const_cast<double *>(Sigma) : h->ws.ws_Sig;
     w.yhe = (yhat && c.m) ? yhat : h->ws.ws_yhe;
@@ -645,6 +655,7 @@ static Workspace group_view(const Workspace &w, const DevCfg &c, int g, int lo, 
     const size_t soff = 2 * (size_t)lo + 64 * (size_t)g; // disjoint slot intervals inside the shared scratch
     v.trajx = w.trajx + soff; v.useq = w.useq + soff; v.stage_L = w.stage_L + soff; v.jac = w.jac + soff;
     v.agent_of = w.agent_of + soff;
+    if (w.arrive) v.arrive = w.arrive + soff / 64;
     v.lists = w.lists + lo;
     v.counts = w.counts + 8 * g;
     v.B = hi - lo; v.Bp = (v.B + 63) & ~63;
@@ -670,6 +681,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     HIPCHK(hipMemsetAsync(w.counts, 0, 8 * MPC_MAX_GROUPS * sizeof(int) + 8 * sizeof(unsigned long long) +
                                            2 * MPC_MAX_GROUPS * sizeof(int), s));
     hipLaunchKernelGGL(init_kernel, dim3((unsigned)(((size_t)B * REC + 255) / 256)), dim3(256), 0, s, c, w);
+    if (w.arrive) HIPCHK(hipMemsetAsync(h->arrive_buf, 0, sizeof(int) * (size_t)(w.St / 64 + 16), s)); // (a failed launch may have left counts)
     h->rounds = 0; h->evals_grad = 0; h->evals_cost = 0; h->eval_ms = 0.0; h->step_ms = 0.0;
     h->lbfgs_ms = 0.0; h->lbfgs_rows = 0; h->solo_agents = 0;
     for (int k = 0; k < 5; k++) { h->kernel_ms[k] = 0.0; h->kernel_launches[k] = 0; }
@@ -868,6 +880,7 @@ extern "C" int mpc_solve_batch(mpc_handle *h, int B, const double *x0, const dou
     Workspace &w = h->ws;
     w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.xo = U; w.y = lambda; w.psi_direct = nullptr;
     w.cl_boxes = boxes_for(h, cl);
+    w.arrive = h->arrive_adjoint ? h->arrive_buf : nullptr;
     w.xe = w.ws_xe; w.ge = w.ws_ge; w.yhe = w.ws_yhe; w.Sig = w.ws_Sig;
     rc = run_solver(h, s); if (rc) return rc;
     if (stats) hipLaunchKernelGGL(stats_kernel, grid_for(B, 256), dim3(256), 0, s, w, stats);

@@ -462,6 +462,14 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
     }
 }
 
+// K1b.  With `w.arrive` set it also does K1c for a block of 64 slots, in the stage-block that finishes
+// last (arrival counter per slot block): the records are stored write-through (sc1: relaxed
+// agent-scope atomic stores, so no release fence), the wave drains its stores, one lane adds to the
+// counter, and the wave whose add returns N - 1 -- every other stage of these slots has then drained
+// its stores before its own add -- invalidates its L1 (agent-scope acquire) and runs the adjoint
+// recursion of its 64 slots with plain loads (the recipe of cdna_hip_programming.md, Guideline 16 R1 in
+// its counter form).  No wave waits for another one.  The adjoint launch and its place in a round's
+// chain of dependent launches disappear; the arithmetic is adjoint_rec either way: same bits.
 template <int MODEL, bool SHARED_CL>
 __global__ void __launch_bounds__(64)
 stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
@@ -474,22 +482,43 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
     const bool is_g = sb < sm.nblk_g;
     const int uslot = sb * 64 + threadIdx.x;
     const int raw = w.agent_of[uslot];
-    if (raw < 0) return;
+    const bool arr = w.arrive != nullptr;                // uniform
+    if (raw < 0 && !arr) return;
     const int a = raw & AGENT_MASK;
     const bool ch2 = (raw & CH2_BIT) != 0;   // speculative channel: only the gradient is kept
     const size_t St = (size_t)w.St;
-    double xs[NX], xe[NX];
+    if (raw >= 0) {
+        double xs[NX], xe[NX];
 #pragma unroll
-    for (int i = 0; i < NX; i++) {
-        xs[i] = w.trajx[(size_t)(k * NX + i) * St + uslot];
-        xe[i] = w.trajx[(size_t)((k + 1) * NX + i) * St + uslot];
+        for (int i = 0; i < NX; i++) {
+            xs[i] = w.trajx[(size_t)(k * NX + i) * St + uslot];
+            xe[i] = w.trajx[(size_t)((k + 1) * NX + i) * St + uslot];
+        }
+        const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
+        const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
+        double *const jr = w.jac + (size_t)k * JS * St + uslot;
+        double *const sl = w.stage_L + (size_t)k * St + uslot;
+        stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, box_row(c, w, SHARED_CL ? 0 : w.cl_index[a]),
+                            [=](int f, double v) {
+                                double *p = f == JS ? sl : jr + (size_t)f * St;
+                                if (arr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                else *p = v;
+                            });
     }
-    const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
-    const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
-    double *const jr = w.jac + (size_t)k * JS * St + uslot;
-    double *const sl = w.stage_L + (size_t)k * St + uslot;
-    stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, box_row(c, w, SHARED_CL ? 0 : w.cl_index[a]),
-                        [=](int f, double v) { if (f == JS) *sl = v; else jr[(size_t)f * St] = v; });
+    if (!arr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's record stores have left
+    int old = 0;
+    if (threadIdx.x == 0) old = __hip_atomic_fetch_add(&w.arrive[sb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != c.N - 1) return;                          // uniform: not the last stage of this slot block
+    if (threadIdx.x == 0) __hip_atomic_store(&w.arrive[sb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale L1 lines of the record block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (raw < 0) return;
+    const double *const jac = w.jac + uslot, *const slp = w.stage_L + uslot;
+    adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int kk, int f) {
+        return f == JS ? slp[(size_t)kk * St] : jac[((size_t)kk * JS + f) * St];
+    });
 }
 
 template <int MODEL>

@@ -57,6 +57,7 @@ struct Workspace {
     double *stage_L;                               // [N][St]        stage costs (+ ALM terms)
     double *jac;                                   // [N*JS][St]     dL/dx, dL/du, stage sensitivities
     int *agent_of;                                 // [St]           agent of a slot (-1: none)
+    int *arrive;                                   // [St / 64]      stage blocks done per slot block (K1c inside K1b), or null
     const double *cl;                              // [C][2S]
     const int *cl_index;                           // [B] or null
     const double *cl_boxes;                        // [C][NB][4] block bounding boxes of the centerline rows, or null

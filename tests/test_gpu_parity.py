@@ -478,8 +478,12 @@ def test_wide_rollout_is_bit_identical(dev, monkeypatch, N):
     assert torch.equal(Uw, Us) and torch.equal(stw, sts) and es.last_solve_info()["spec_issued"] == 0
     monkeypatch.setenv("MPC_UNFUSED_EVAL", "1")                          # K1b and K1c as two launches
     Uu, _, stu = mp.BatchedMPC(cfg, dev).solve(X0, cl, U0)
-    monkeypatch.delenv("MPC_UNFUSED_EVAL")
     assert torch.equal(Uw, Uu) and torch.equal(stw, stu)
+    monkeypatch.setenv("MPC_ARRIVE", "1")                                # ... K1c inside K1b's last-arriving stage block
+    Uv, _, stv = mp.BatchedMPC(cfg, dev).solve(X0, cl, U0)               # (arrival counters, write-through records)
+    monkeypatch.delenv("MPC_ARRIVE")
+    monkeypatch.delenv("MPC_UNFUSED_EVAL")
+    assert torch.equal(Uw, Uv) and torch.equal(stw, stv)
     monkeypatch.setenv("MPC_APB", "64")                                  # 64 agents per step workgroup, not 4
     Ua, _, sta = mp.BatchedMPC(cfg, dev).solve(X0, cl, U0)
     monkeypatch.delenv("MPC_APB")
