@@ -870,6 +870,35 @@ def test_two_player_iterated_best_response(dev, O):
     assert (res["stats"][:, 0] == 1).all()
 
 
+def test_config5_full_size_properties(dev):
+    """BASELINE.json config 5 at one GPU's share: 32768 pairs of players (65536 solves per best-response
+    round, N = 20, kinematic model), no evaluation budget.  Oracle-free properties of the build-defined
+    loop: decisions are lanes, only a lane-1 player that targets lane 2 gets the lane-change centerline,
+    (nearly) every solve converges, the loop is deterministic and both players of a pair are solved
+    independently of the rest of the batch."""
+    from model_predictive_control_amd import game_theory as gt
+    P, K = 32768, 4
+    rng = np.random.default_rng(0)
+    game = gt.TwoPlayerLaneChange(N=20, device=dev, max_total_inner=600)
+    gs = np.zeros((P, 2, 3)); gs[:, 0] = np.stack([rng.uniform(-5, 5, P), rng.uniform(8, 14, P), np.ones(P)], 1)
+    gs[:, 1] = np.stack([rng.uniform(-30, 30, P), rng.uniform(8, 16, P), rng.integers(1, 3, P)], 1)
+    xm = np.zeros((P, 2, 4)); xm[:, :, 0] = rng.uniform(0, 1, (P, 2)); xm[:, :, 3] = rng.uniform(.5, 1.0, (P, 2))
+    traffic = np.stack([rng.uniform(-60, 80, (P, K)), rng.uniform(0, 20, (P, K)), rng.integers(1, 3, (P, K))], 2).astype(float)
+    ntr = rng.integers(0, K + 1, P).astype(np.int32)
+    out = game.play(gs, xm, traffic, ntr, rounds=4)
+    tgt, st = out["target"], out["stats"]
+    assert 1 <= out["rounds"] <= 4 and set(tgt.unique().tolist()) <= {1, 2}
+    assert (tgt != torch.tensor(gs[:, :, 2], device=dev).to(torch.int32)).any()         # somebody changes lane
+    assert (st[:, 0] == 1).double().mean().item() >= 0.999 and set(st[:, 0].unique().tolist()) <= {1.0, 2.0}
+    assert st[:, 7].max().item() <= 20000 and torch.isfinite(out["U"]).all()
+    out2 = game.play(gs, xm, traffic, ntr, rounds=4)
+    assert torch.equal(out2["target"], tgt) and torch.equal(out2["U"], out["U"]) and out2["rounds"] == out["rounds"]
+    sub = slice(1000, 1000 + 2048)                                                       # pairs do not see other pairs
+    out3 = game.play(gs[sub], xm[sub], traffic[sub], ntr[sub], rounds=4)
+    if out3["rounds"] == out["rounds"]:
+        assert torch.equal(out3["target"], tgt[sub]) and torch.equal(out3["U"], out["U"][sub])
+
+
 # ----------------------------------------------------------------------------- host interface
 def test_controller_drop_in_and_closed_loop(dev, O, orc_golden):
     """a-13: MPCController.__call__ mirrors controller.py:51-69; main.py's closed loop reproduces
