@@ -114,6 +114,7 @@ def main():
                     help="inner-iteration budget per solve (stands in for controller.py:30,:44 wall-clock caps); "
                          "0 = the library default (5000)")
     ap.add_argument("--max-total-evals", type=int, default=0, help="evaluation budget per solve (0 = none)")
+    ap.add_argument("--lbfgs-memory", type=int, default=0, help="L-BFGS memory (0 = the reference's: N_horiz, controller.py:36)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true",
@@ -149,6 +150,8 @@ def main():
         cfg_kw["max_total_inner"] = args.max_total_inner
     if args.max_total_evals > 0:
         cfg_kw["max_total_evals"] = args.max_total_evals
+    if args.lbfgs_memory > 0:
+        cfg_kw["lbfgs_memory"] = args.lbfgs_memory
     cfg = mp.default_config(args.model, N, **cfg_kw)
     eng = mp.BatchedMPC(cfg, dev)
     eng.set_profile(bool(args.profile_timed))
