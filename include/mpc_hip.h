@@ -182,9 +182,10 @@ int mpc_last_kernel_ms(mpc_handle *h, double *out4);
  * solo_agents = agents that finished in the persistent wave-per-agent kernel.  Any pointer may be NULL. */
 int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int64_t *solo_agents);
 /* A sub-batch group whose round holds at most `max_requests` evaluation requests leaves the rounds
- * and finishes in the persistent wave-per-agent kernel; batches up to that size use it from the
- * start (0 = rounds only; default 1024 for the kinematic model with N <= 32 and 0 otherwise -- measured,
- * DESIGN.md 5; environment MPC_SOLO_MAX).  Results do not depend on it. */
+ * and finishes in the persistent wave-per-agent kernel, and a batch of at most `max_requests` agents runs in
+ * it from the start (0 = rounds only).  Defaults (measured): switch at 1024 requests for
+ * N <= 32, never beyond; whole batches up to 4096 agents (kinematic) / 1024 (Pacejka); environment
+ * MPC_SOLO_MAX (both) and MPC_SOLO_ALL (the batch bound alone).  Results do not depend on it. */
 int mpc_set_solo_max(mpc_handle *h, int max_requests);
 /* sub-batch pipelining: the batch is split into `groups` contiguous ranges whose rounds run on
  * separate HIP streams (0 = automatic: 3 from 24576 agents, 2 from 16384, else 1; at most 8) */

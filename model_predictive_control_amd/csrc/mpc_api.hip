@@ -47,6 +47,8 @@ struct mpc_handle {
     int cl_boxes_rows = 0;
     bool nearest_blocks = false;          // MPC_NEAREST_BLOCKS / mpc_set_nearest_blocks: the pruned search (same
                                           // index; measured slower than the full scan: profiles/r02_nearest_blocks.txt)
+    int solo_all = 4096;        // a batch of at most this many agents runs in the persistent kernel from the start
+                                // (MPC_SOLO_ALL; measured: kinematic 4 096 agents 62.8 -> 53.3 ms, 8 192 worse; Pacejka 1 024)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
                                 // wave-per-agent kernel (MPC_SOLO_MAX / mpc_set_solo_max; 0 = rounds only).
                                 // Default: 1024 for the kinematic model up to N = 32; 0 otherwise (measured:
@@ -194,7 +196,9 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
     h->solo_max = cfg->N <= 32 ? 1024 : 0;
-    if (getenv("MPC_SOLO_MAX")) h->solo_max = atoi(getenv("MPC_SOLO_MAX"));
+    h->solo_all = cfg->N > 32 ? 0 : cfg->model == MPC_MODEL_KINEMATIC ? 4096 : 1024;
+    if (getenv("MPC_SOLO_MAX")) h->solo_max = h->solo_all = atoi(getenv("MPC_SOLO_MAX"));
+    if (getenv("MPC_SOLO_ALL")) h->solo_all = atoi(getenv("MPC_SOLO_ALL"));
     h->nearest_blocks = getenv("MPC_NEAREST_BLOCKS") != nullptr;
     h->cfg = *cfg;
     int rc = make_devcfg(*cfg, h->dc);
@@ -606,7 +610,7 @@ static void launch_solo_t(mpc_handle *h, const Workspace &v, hipStream_t s, int 
         hipLaunchKernelGGL(solo_list_kernel, dim3((unsigned)((v.B + 255) / 256)), dim3(256), 0, s, v, list, ctr);
     const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.nfe, c.N, c.n, c.M, MC < 0);
     int nblk = (bound + SOLO_WAVES - 1) / SOLO_WAVES;
-    nblk = std::max(1, std::min(nblk, 4 * h->num_cus)); // one wave per SIMD is resident (registers); the rest queues
+    nblk = std::max(1, std::min(nblk, 4 * SoloOcc<MODEL>::WPS * h->num_cus)); // what is resident (registers); the rest queues
     hipLaunchKernelGGL((solo_kernel<MODEL, NE, MC>), dim3((unsigned)nblk), dim3(64 * SOLO_WAVES), lds, s, c, v, list,
                        ctr, max_trips);
 }
@@ -692,7 +696,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     const long long per_iter = 700;
     long long max_rounds = per_iter * ((long long)c.max_total_inner + 16) + 8LL * c.max_outer + 1024;
     if (c.max_total_evals > 0) max_rounds = std::min(max_rounds, (long long)c.max_total_evals + per_iter + 8LL * c.max_outer + 1024);
-    const bool solo_ok = h->solo_max > 0 && solo_fits(h);
+    const bool solo_ok = (h->solo_max > 0 || h->solo_all > 0) && solo_fits(h);
     size_t nev = 0;               // events 0 .. nev-1 of the pool: five per sampled launch set
     bool solo_timed[MPC_MAX_GROUPS] = {false};
     auto solo_events = [&](int g, hipStream_t st, int which) { // profile mode: (start, stop) around the launch
@@ -705,7 +709,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     long long rounds_done[MPC_MAX_GROUPS] = {0};
     int ng = 0;
     bool all_solo = false;
-    if (solo_ok && B <= h->solo_max) {
+    if (solo_ok && B <= h->solo_all) {
         // small batch: every agent is solved by one wave of the persistent kernel from the start
         all_solo = true;
     }
@@ -803,7 +807,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
                     polled[pb][g] = false;
                     if (reqs == 0) { active[g] = false; nactive--; continue; }
                     slot_bound[g] = std::min(slot_bound[g], 2 * reqs);
-                    if (solo_ok && reqs <= h->solo_max) {
+                    if (solo_ok && h->solo_max > 0 && reqs <= h->solo_max) {
                         // few agents left in this group: they finish in the persistent kernel, each in
                         // its own wave, instead of waiting for four launches per evaluation
                         solo_events(g, gs[g], 0);
@@ -974,7 +978,7 @@ extern "C" int mpc_set_nearest_blocks(mpc_handle *h, int on)
 extern "C" int mpc_set_solo_max(mpc_handle *h, int max_requests)
 {
     if (!h || max_requests < 0) return fail(MPC_E_ARG, "mpc_set_solo_max: bad argument");
-    h->solo_max = max_requests;
+    h->solo_max = h->solo_all = max_requests;
     return MPC_OK;
 }
 

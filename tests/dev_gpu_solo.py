@@ -19,7 +19,8 @@ for B in sizes:
     ref = None
     for th in thresholds:
         eng = mp.BatchedMPC(mp.default_config(model, N, max_total_evals=evals), dev)
-        eng.set_solo_max(th)
+        if th >= 0:            # negative: the library's defaults
+            eng.set_solo_max(th)
         eng.solve(X0, cl, U0)
         ts = []
         for _ in range(3):
