@@ -35,6 +35,8 @@ def counter_rows(sub):
 # ---- 1. kernel stats
 for f in glob.glob(os.path.join(OUT, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(PROF, tag + "_kernel_stats.csv"))
+for f in glob.glob(os.path.join(OUT, "stats_groups1", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(PROF, tag + "_kernel_stats_groups1.csv"))
 for name in ("bench_under_rocprof.json",):
     if os.path.exists(os.path.join(OUT, name)):
         shutil.copy(os.path.join(OUT, name), os.path.join(PROF, tag + "_" + name))

@@ -20,6 +20,9 @@ echo fetch done
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 $B > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 echo write done
 export MPC_GROUPS=1
+# the same statistics on ONE stream: what bench.py's per-kernel figures (its untimed single-group pass) must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_groups1 -- python3 $R/bench.py --steps 2 --warmup 1 $B > $OUT/bench_groups1_under_rocprof.json 2> $OUT/stats_groups1.err
+echo stats groups1 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 1 --warmup 0 $B > $OUT/bench_sq.json 2> $OUT/sq.err || true
 echo sq done
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_solo -- python3 $R/bench.py --steps 1 --warmup 1 $B > $OUT/bench_trace_solo.json 2> $OUT/trace_solo.err
