@@ -183,8 +183,8 @@ int mpc_last_kernel_ms(mpc_handle *h, double *out4);
 int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int64_t *solo_agents);
 /* A sub-batch group whose round holds at most `max_requests` evaluation requests leaves the rounds
  * and finishes in the persistent wave-per-agent kernel, and a batch of at most `max_requests` agents runs in
- * it from the start (0 = rounds only).  Defaults (measured): switch at 1024 requests for
- * N <= 32, never beyond; whole batches up to 4096 agents (kinematic) / 1024 (Pacejka); environment
+ * it from the start (0 = rounds only).  Defaults (measured): switch at 1024 requests; whole
+ * batches up to 4096 agents (kinematic, N <= 32) / 1024 (otherwise); environment
  * MPC_SOLO_MAX (both) and MPC_SOLO_ALL (the batch bound alone).  Results do not depend on it. */
 int mpc_set_solo_max(mpc_handle *h, int max_requests);
 /* sub-batch pipelining: the batch is split into `groups` contiguous ranges whose rounds run on

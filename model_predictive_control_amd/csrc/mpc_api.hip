@@ -51,9 +51,7 @@ struct mpc_handle {
                                 // (MPC_SOLO_ALL; measured: kinematic 4 096 agents 62.8 -> 53.3 ms, 8 192 worse; Pacejka 1 024)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
                                 // wave-per-agent kernel (MPC_SOLO_MAX / mpc_set_solo_max; 0 = rounds only).
-                                // Default: 1024 for the kinematic model up to N = 32; 0 otherwise (measured:
-                                // the Pacejka rollout is one serial chain whichever kernel runs it, and a wave
-                                // evaluates its agent's two requests of a round one after the other)
+                                // Default 1024 (measured for both models and for N = 40: profiles/r02c_*)
     int Bp_alloc = 0;      // workspace capacity (agents)
     char *arena = nullptr; // one device allocation carved into the Workspace arrays
     size_t arena_bytes = 0;
@@ -195,8 +193,8 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
-    h->solo_max = cfg->N <= 32 ? 1024 : 0;
-    h->solo_all = cfg->N > 32 ? 0 : cfg->model == MPC_MODEL_KINEMATIC ? 4096 : 1024;
+    h->solo_max = 1024;
+    h->solo_all = (cfg->model == MPC_MODEL_KINEMATIC && cfg->N <= 32) ? 4096 : 1024;
     if (getenv("MPC_SOLO_MAX")) h->solo_max = h->solo_all = atoi(getenv("MPC_SOLO_MAX"));
     if (getenv("MPC_SOLO_ALL")) h->solo_all = atoi(getenv("MPC_SOLO_ALL"));
     h->nearest_blocks = getenv("MPC_NEAREST_BLOCKS") != nullptr;
