@@ -182,6 +182,11 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
 extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
 {
     if (!cfg || !out) return fail(MPC_E_ARG, "mpc_create: null argument");
+    {   // the configuration is checked before anything touches the device (and without one: CPU tests)
+        DevCfg probe;
+        const int rcv = make_devcfg(*cfg, probe);
+        if (rcv) return rcv;
+    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(MPC_E_ARG, "mpc_create: no such device");

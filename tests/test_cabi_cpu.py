@@ -83,6 +83,30 @@ def test_bad_arguments_return_codes_not_exceptions(L):
         mp.default_config(mp.MODEL_PACEJKA, 1000)
 
 
+def test_config_is_validated_before_the_device_is_touched(L):
+    """mpc_create refuses a configuration the kernels cannot run with MPC_E_ARG (-1) -- checked before any
+    HIP call, so it holds without a GPU: non-positive iteration limits (a negative budget used to end as
+    'round limit reached'), Sigma_0 = 0 (alpaqa's separate initial-penalty path is not restated: the
+    kernels divide by Sigma), inverted Lipschitz or box bounds, non-positive Ts."""
+    bad = [dict(max_total_inner=-5), dict(max_iter=0), dict(max_outer=0), dict(Sigma0=0.0), dict(Sigma0=-1.0),
+           dict(L_min=1.0, L_max=0.5), dict(Ts=0.0), dict(Ts=float("nan")), dict(tau_min=0.0), dict(max_total_evals=-1),
+           dict(u_lb=[1.0, 0.0], u_ub=[-1.0, 0.3]), dict(S=2), dict(nfe=0), dict(lbfgs_memory=0), dict(alm_eps=0.0)]
+    for kw in bad:
+        cfg = mp.default_config(mp.MODEL_KINEMATIC, 20, **kw)
+        h = C.c_void_p()
+        assert L.mpc_create(C.byref(cfg), 0, C.byref(h)) == -1, kw
+        assert L.mpc_last_error()
+    # a valid configuration gets past the check (and then fails on the missing device, or succeeds)
+    cfg = mp.default_config(mp.MODEL_KINEMATIC, 20)
+    h = C.c_void_p()
+    rc = L.mpc_create(C.byref(cfg), 0, C.byref(h))
+    assert rc in (0, -1, -2)
+    if rc == 0:
+        L.mpc_destroy(h)
+    else:
+        assert b"mpc_create" in L.mpc_last_error() or b"hip" in L.mpc_last_error().lower()
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
