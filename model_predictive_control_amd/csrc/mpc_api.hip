@@ -613,7 +613,7 @@ static void launch_solo_t(mpc_handle *h, const Workspace &v, hipStream_t s, int 
         hipLaunchKernelGGL(solo_list_kernel, dim3((unsigned)((v.B + 255) / 256)), dim3(256), 0, s, v, list, ctr);
     const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.nfe, c.N, c.n, c.M, MC < 0);
     int nblk = (bound + SOLO_WAVES - 1) / SOLO_WAVES;
-    nblk = std::max(1, std::min(nblk, 4 * SoloOcc<MODEL>::WPS * h->num_cus)); // what is resident (registers); the rest queues
+    nblk = std::max(1, std::min(nblk, 4 * SoloOcc<MODEL, MC>::WPS * h->num_cus)); // what is resident (registers); the rest queues
     hipLaunchKernelGGL((solo_kernel<MODEL, NE, MC>), dim3((unsigned)nblk), dim3(64 * SOLO_WAVES), lds, s, c, v, list,
                        ctr, max_trips);
 }

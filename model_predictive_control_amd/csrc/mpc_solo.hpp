@@ -135,10 +135,11 @@ __global__ void __launch_bounds__(64, 1) solo_eval_kernel(const DevCfg c, const 
 // waves per SIMD) it spills ~90 of them and a lone wave is no slower for it (1 024 agents: 32.5 vs 33.1 ms),
 // while twice as many agents are in flight (4 096 agents: 78 -> 53 ms).  The Pacejka variant needs all 512
 // and its long serial chains lose more to the spills than they gain (65 536 agents: 0.97 -> 1.01 s): one wave.
-template <int MODEL> struct SoloOcc { static constexpr int WPS = MODEL == KIN ? 2 : 1; };
+// (the variant that caches twenty history pairs in registers cannot be held to 256 either)
+template <int MODEL, int MC> struct SoloOcc { static constexpr int WPS = (MODEL == KIN && MC <= 0) ? 2 : 1; };
 
 template <int MODEL, int NE, int MC>
-__global__ void __launch_bounds__(64 * SOLO_WAVES, SoloOcc<MODEL>::WPS)
+__global__ void __launch_bounds__(64 * SOLO_WAVES, SoloOcc<MODEL, MC>::WPS)
 solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int *__restrict__ ctr,
             long long max_trips)
 {

@@ -120,10 +120,20 @@ __device__ __forceinline__ double row_sum16(double v)
     return v;
 }
 __device__ __forceinline__ double scan_sum(double v) { return row_sum16(v); }
+// The four row totals are added as (r0 + r1) + (r2 + r3).  A vector of n <= 48 (<= 32) elements leaves
+// row 3 (rows 2 and 3) all zero: their totals are skipped -- adding an exact zero changes no bit -- and
+// with them two (four) SGPR reads and an addition per sum (NROWS is what the caller knows about n).
+template <int NROWS = 4>
+__device__ __forceinline__ double cross_rows(double v)
+{
+    if (NROWS <= 2) return rdlane(v, 0) + rdlane(v, 16);
+    if (NROWS == 3) return (rdlane(v, 0) + rdlane(v, 16)) + rdlane(v, 32);
+    return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
     v = row_sum16(v);
-    return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+    return cross_rows<4>(v);
 }
 #endif
 // reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp): the IEEE division sequence costs ~6x more
@@ -146,12 +156,26 @@ __device__ __forceinline__ void wave_sum3(double &a, double &b, double &c)
     a = scan_sum(a); b = scan_sum(b); c = scan_sum(c);
     a = rdlane(a, 63); b = rdlane(b, 63); c = rdlane(c, 63);
 }
+__device__ __forceinline__ double wave_sum_n(double v, int) { return wave_sum(v); }
+__device__ __forceinline__ void wave_sum2_n(double &a, double &b, int) { wave_sum2(a, b); }
 #else
 __device__ __forceinline__ void wave_sum2(double &a, double &b)
 {
     a = row_sum16(a); b = row_sum16(b);
-    a = (rdlane(a, 0) + rdlane(a, 16)) + (rdlane(a, 32) + rdlane(a, 48));
-    b = (rdlane(b, 0) + rdlane(b, 16)) + (rdlane(b, 32) + rdlane(b, 48));
+    a = cross_rows<4>(a); b = cross_rows<4>(b);
+}
+// sums of vectors whose elements beyond n are exact zeros (one element per lane: NE = 1), n wave-uniform
+__device__ __forceinline__ double wave_sum_n(double v, int n)
+{
+    v = row_sum16(v);
+    return n <= 32 ? cross_rows<2>(v) : n <= 48 ? cross_rows<3>(v) : cross_rows<4>(v);
+}
+__device__ __forceinline__ void wave_sum2_n(double &a, double &b, int n)
+{
+    a = row_sum16(a); b = row_sum16(b);
+    if (n <= 32) { a = cross_rows<2>(a); b = cross_rows<2>(b); }
+    else if (n <= 48) { a = cross_rows<3>(a); b = cross_rows<3>(b); }
+    else { a = cross_rows<4>(a); b = cross_rows<4>(b); }
 }
 __device__ __forceinline__ void wave_sum3(double &a, double &b, double &c)
 {
@@ -246,7 +270,7 @@ __device__ __forceinline__ void prox_to_xe(const DevCfg &c, double *__restrict__
         if (lane + 64 * e < n) { a = fma(p, p, a); b = fma(gb.v[e], p, b); }
     }
     strow<NE>(xe, n, lane, xh);
-    wave_sum2(a, b);
+    wave_sum2_n(a, b, n);
     pp = a; gp = b;
 }
 
@@ -312,7 +336,7 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
         double sy = 0.0, sq = 0.0;
 #pragma unroll
         for (int e = 0; e < NE; e++) { sy = fma(s.v[e], y.v[e], sy); sq = fma(s.v[e], q.v[e], sq); }
-        wave_sum2(sy, sq);
+        wave_sum2_n(sy, sq, n);
         const double rho = fast_rcp(sy);
         if (!(rho > 0.0)) return;          // lane t keeps rho_t = -1
         const double al = rho * sq;
@@ -323,7 +347,7 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
             double yy = 0.0;
 #pragma unroll
             for (int e = 0; e < NE; e++) yy = fma(y.v[e], y.v[e], yy);
-            h0 = 1.0 / (rho * wave_sum(yy));
+            h0 = 1.0 / (rho * wave_sum_n(yy, n));
         }
     };
     auto second_loop = [&](int t, const Row<NE> &s, const Row<NE> &y) {
@@ -332,7 +356,7 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
         double yq = 0.0;
 #pragma unroll
         for (int e = 0; e < NE; e++) yq = fma(y.v[e], q.v[e], yq);
-        yq = wave_sum(yq);
+        yq = wave_sum_n(yq, n);
         const double ab = rdlane(alpha_v, t) - rho * yq;
 #pragma unroll
         for (int e = 0; e < NE; e++) q.v[e] = fma(ab, s.v[e], q.v[e]);
@@ -519,7 +543,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             qv.v[e] = in ? 0.0 : prox_p(c, par, XN.v[e], GE.v[e], gm);
             if (valid) { cntJ += in ? 1.0 : 0.0; xx += XN.v[e] * XN.v[e]; }
         }
-        wave_sum2(cntJ, xx);
+        wave_sum2_n(cntJ, xx, n);
         const int nj = (int)cntJ;
         spec = 0;
         if (nj > 0 && nj < n) {
@@ -563,7 +587,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             }
             X = x;
             strow<NE>(w.xk + an, n, lane, x); strow<NE>(w.xe + an, n, lane, xh);
-            hn2 = wave_sum(s);
+            hn2 = wave_sum_n(s, n);
             req = REQ_GRAD; phase = PH_W_INIT_H;
         } break;
         case PH_W_INIT_H: {
@@ -580,7 +604,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             for (int e = 0; e < NE; e++) { const double dd = gh.v[e] - g.v[e]; s += dd * dd; }
             G = g;
             strow<NE>(w.gk + an, n, lane, g);
-            const double dn2 = wave_sum(s);
+            const double dn2 = wave_sum_n(s, n);
             // std::clamp semantics: a NaN estimate stays NaN (fmin/fmax would turn it into L_min)
             const double L0 = sqrt(dn2) / sqrt(hn2);
             Lk = L0 < c.L_min ? c.L_min : (c.L_max < L0 ? c.L_max : L0);
@@ -618,7 +642,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                 double s = 0.0;
 #pragma unroll
                 for (int e = 0; e < NE; e++) s += x.v[e] * x.v[e];
-                const double h = cbrt(DBL_EPSILON) * (1.0 + sqrt(wave_sum(s)));
+                const double h = cbrt(DBL_EPSILON) * (1.0 + sqrt(wave_sum_n(s, n)));
                 Row<NE> xh;
 #pragma unroll
                 for (int e = 0; e < NE; e++) xh.v[e] = x.v[e] + h * g.v[e];
@@ -637,7 +661,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                 const double Hv = (gh.v[e] - g.v[e]) / hfd;
                 gHg += g.v[e] * Hv; gg += g.v[e] * g.v[e];
             }
-            wave_sum2(gHg, gg);
+            wave_sum2_n(gHg, gg, n);
             const double eta = gg / gHg;
             if (eta > 0.0 && isfinite(eta) && eta * c.Lgamma > gamma) {
                 Lk = 1.0 / eta;
@@ -692,7 +716,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                     qv.v[e] = in ? 0.0 : prox_p(c, par, x.v[e], g.v[e], gamma);
                     if (valid) { cntJ += in ? 1.0 : 0.0; xx += x.v[e] * x.v[e]; }
                 }
-                wave_sum2(cntJ, xx);
+                wave_sum2_n(cntJ, xx, n);
                 nJ = (int)cntJ;
                 // (the q row is written once, by PH_LS_INIT -- or below when the step ends here: every
                 // store issued before the wait for the history would be drained by it)
@@ -822,7 +846,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                     ys += yv.v[e] * s.v[e]; ss += s.v[e] * s.v[e];
                     same = same && (xp.v[e] == x.v[e]);
                 }
-                wave_sum2(ys, ss);
+                wave_sum2_n(ys, ss, n);
                 const bool all_same = __ballot(!same) == 0ull;
                 // the pair goes into the free ring slot; it joins the history only if the
                 // curvature test accepts it
