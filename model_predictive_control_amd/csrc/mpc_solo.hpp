@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64, 1) solo_eval_kernel(const DevCfg c, const 
 template <int MODEL, int MC> struct SoloOcc { static constexpr int WPS = (MODEL == KIN && MC <= 0) ? 2 : 1; };
 
 template <int MODEL, int NE, int MC>
-__global__ void __launch_bounds__(64 * SOLO_WAVES, SoloOcc<MODEL, MC>::WPS)
+__global__ void __launch_bounds__(64 * SOLO_WAVES, (SoloOcc<MODEL, MC>::WPS))
 solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int *__restrict__ ctr,
             long long max_trips)
 {
