@@ -32,7 +32,15 @@ def gather_controls(local, B_total, dst=0, group=None):
     # once, only `dst` receives -- 1/world of the bytes an all_gather would move over xGMI
     dst_global = dst if group is None else dist.get_global_rank(group, dst)
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, gather_list=bufs, dst=dst_global, group=group)
+    try:
+        dist.gather(pad, gather_list=bufs, dst=dst_global, group=group)
+    except (RuntimeError, NotImplementedError) as exc:
+        # a backend build without gather refuses the call on every rank alike, before anything is sent:
+        # the all_gather below is then the one code path all ranks take
+        if "gather" not in str(exc).lower() and "not supported" not in str(exc).lower() and "implemented" not in str(exc).lower():
+            raise
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
     if rank != dst:
         return None
     return torch.cat([bufs[r][:hi - lo] for r, (lo, hi) in enumerate(sizes)], 0).to(local.device)
