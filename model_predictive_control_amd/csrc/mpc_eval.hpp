@@ -119,7 +119,14 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     if (half == 0 && uslot < nslots) w.agent_of[uslot] = raw;
     if (active) {
         const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)(raw & AGENT_MASK) * n;
-        for (int j = half; j < n; j += 2) lds[q * ld + j] = row[j];
+        // eight loads in flight per lane before the first LDS write (one at a time = one memory round trip each)
+        for (int j0 = half; j0 < n; j0 += 16) {
+            double v[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) v[t] = j0 + 2 * t < n ? row[j0 + 2 * t] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) if (j0 + 2 * t < n) lds[q * ld + j0 + 2 * t] = v[t];
+        }
     }
     __builtin_amdgcn_wave_barrier();                     // one wave per workgroup: LDS is in order
     if (!active) return;                                 // whole pairs leave together
@@ -198,7 +205,13 @@ rollout_quad_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     // stage in: the quad's own row, four elements per trip
     if (active) {
         const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)(raw & AGENT_MASK) * n;
-        for (int j = role; j < n; j += 4) lds[q * ld + j] = row[j];
+        for (int j0 = role; j0 < n; j0 += 32) {          // eight loads in flight per lane before the first LDS write
+            double v[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) v[t] = j0 + 4 * t < n ? row[j0 + 4 * t] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) if (j0 + 4 * t < n) lds[q * ld + j0 + 4 * t] = v[t];
+        }
     }
     __builtin_amdgcn_wave_barrier();                     // one wave per workgroup: LDS is in order
     if (!active) return;                                 // whole quads leave together
