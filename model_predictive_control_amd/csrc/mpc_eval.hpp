@@ -483,8 +483,9 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
 // recursion of its 64 slots with plain loads (the recipe of cdna_hip_programming.md, Guideline 16 R1 in
 // its counter form).  No wave waits for another one.  The adjoint launch and its place in a round's
 // chain of dependent launches disappear; the arithmetic is adjoint_rec either way: same bits.
+// (kinematic: held to 168 registers = three waves per SIMD, 144 B of scratch per lane: K1b -3.6 %)
 template <int MODEL, bool SHARED_CL>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (MODEL == KIN ? 3 : 1))
 stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
              int nblk_max)
 {
