@@ -95,14 +95,16 @@ int mpc_rhs(mpc_handle *h, int B, const double *x, const double *u, double *dx, 
 int mpc_rollout(mpc_handle *h, int B, int Nsim, const double *x0, const double *U, double *X,
                 void *stream);
 
-/* f-2 (car_dynamics.py:185-190, the 98-candidate scan per stage): prepares the exact block-pruned
- * nearest-point search for the centerline table cl [C][2S] -- bounding boxes of blocks of 8
- * consecutive points, computed on `stream`.  Later calls that are handed the SAME table pointer
- * (mpc_solve_batch, mpc_eval_cost_grad*, mpc_stage_errors, mpc_closed_loop) use it; any other table
- * takes the full scan.  The index found is the same either way, bit for bit.  Call it again
- * whenever the table's contents change.  The pruned search is OFF by default (it measured 3 % slower
- * than the scalar-load full scan on MI355X: DESIGN.md 8); mpc_set_nearest_blocks(h, 1) or the
- * environment variable MPC_NEAREST_BLOCKS switches it on. */
+/* f-2 (car_dynamics.py:185-190, the 98-candidate scan per stage): prepares the exact pruned
+ * nearest-point searches for the centerline table cl [C][2S], on `stream`: (mode 2) a grid of index
+ * ranges per row -- every cell holds the range [lo, hi] guaranteed to contain the scan's answer for any
+ * point of the cell -- and (mode 1) bounding boxes of blocks of 8 consecutive points.  Later calls that
+ * are handed the SAME table pointer (mpc_solve_batch, mpc_eval_cost_grad*, mpc_stage_errors,
+ * mpc_closed_loop) use the search mpc_set_nearest_blocks selects; any other table takes the full scan.
+ * The index found is the same whichever runs, bit for bit.  Call it again whenever the table's contents
+ * change.  mpc_set_nearest_blocks(h, mode): 0 full scan (environment MPC_NEAREST_SCAN), 1 block boxes
+ * (MPC_NEAREST_BLOCKS; measured 3 % slower than the scan), 2 grid (default; measured 4.8 % faster
+ * solves: DESIGN.md 8). */
 int mpc_centerline_blocks(mpc_handle *h, const double *cl, int C, void *stream);
 int mpc_set_nearest_blocks(mpc_handle *h, int on);
 

@@ -45,8 +45,12 @@ struct mpc_handle {
     size_t cl_boxes_bytes = 0;
     const double *cl_boxes_for = nullptr; // the table they describe (device pointer identity)
     int cl_boxes_rows = 0;
-    bool nearest_blocks = false;          // MPC_NEAREST_BLOCKS / mpc_set_nearest_blocks: the pruned search (same
-                                          // index; measured slower than the full scan: profiles/r02_nearest_blocks.txt)
+    int nearest_mode = 2;                 // mpc_set_nearest_blocks: 0 full scan (MPC_NEAREST_SCAN), 1 block boxes (MPC_NEAREST_BLOCKS;
+                                          // measured slower: profiles/r02_nearest_blocks.txt), 2 grid of index ranges (default);
+                                          // a table that mpc_centerline_blocks has not prepared takes the full scan
+    double *cl_gmeta = nullptr, *cl_gxy = nullptr;   // grid placement [C][GRID_META], interleaved points [C][S][2]
+    unsigned *cl_gcells = nullptr;                   // [C][GRID_CELLS]
+    int cl_grid_cap = 0;                             // rows the grid buffers hold
     int solo_all = 4096;        // a batch of at most this many agents runs in the persistent kernel from the start
                                 // (MPC_SOLO_ALL; measured: kinematic 4 096 agents 62.8 -> 53.3 ms, 8 192 worse; Pacejka 1 024)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
@@ -202,7 +206,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->solo_all = (cfg->model == MPC_MODEL_KINEMATIC && cfg->N <= 32) ? 4096 : 1024;
     if (getenv("MPC_SOLO_MAX")) h->solo_max = h->solo_all = atoi(getenv("MPC_SOLO_MAX"));
     if (getenv("MPC_SOLO_ALL")) h->solo_all = atoi(getenv("MPC_SOLO_ALL"));
-    h->nearest_blocks = getenv("MPC_NEAREST_BLOCKS") != nullptr;
+    h->nearest_mode = getenv("MPC_NEAREST_SCAN") ? 0 : getenv("MPC_NEAREST_BLOCKS") ? 1 : 2;
     h->cfg = *cfg;
     int rc = make_devcfg(*cfg, h->dc);
     if (rc) { delete h; return rc; }
@@ -229,6 +233,9 @@ extern "C" int mpc_destroy(mpc_handle *h)
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
     if (h->cl_boxes) (void)hipFree(h->cl_boxes);
+    if (h->cl_gmeta) (void)hipFree(h->cl_gmeta);
+    if (h->cl_gxy) (void)hipFree(h->cl_gxy);
+    if (h->cl_gcells) (void)hipFree(h->cl_gcells);
     if (h->host_counts) (void)hipHostFree(h->host_counts);
     for (auto ev : h->ev_pool) (void)hipEventDestroy(ev);
     for (int g = 0; g < MPC_MAX_GROUPS; g++) if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
@@ -348,8 +355,9 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         if (evb) (void)hipEventRecord(evb, s);
         return true;
     }
+    const size_t xy_lds = (shared && w.near.gmeta) ? sizeof(double) * 2 * (size_t)c.S : 0;
     if (shared)
-        hipLaunchKernelGGL((stage_kernel<MODEL, true>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
+        hipLaunchKernelGGL((stage_kernel<MODEL, true>), dim3((unsigned)(nblk * c.N)), dim3(64), xy_lds, s, c, w, counts, nG, nC, nblk);
     else
         hipLaunchKernelGGL((stage_kernel<MODEL, false>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
     if (evb) (void)hipEventRecord(evb, s);
@@ -373,10 +381,14 @@ static int check_common(mpc_handle *h, int B, const char *who)
     return MPC_OK;
 }
 
-// the boxes to use with centerline table `cl` (null: none prepared for it, or switched off)
-static const double *boxes_for(const mpc_handle *h, const double *cl)
+// the search tables to use with centerline table `cl` (all null: none prepared for it, or switched off)
+static NearTab near_for(const mpc_handle *h, const double *cl)
 {
-    return (h->nearest_blocks && h->cl_boxes && h->cl_boxes_for == cl) ? h->cl_boxes : nullptr;
+    NearTab nt = {nullptr, nullptr, nullptr, nullptr};
+    if (!h->cl_boxes_for || h->cl_boxes_for != cl) return nt;
+    if (h->nearest_mode == 1 && h->cl_boxes) nt.boxes = h->cl_boxes;
+    if (h->nearest_mode == 2 && h->cl_gmeta) { nt.gmeta = h->cl_gmeta; nt.gcells = h->cl_gcells; nt.gxy = h->cl_gxy; }
+    return nt;
 }
 
 extern "C" int mpc_centerline_blocks(mpc_handle *h, const double *cl, int C, void *stream)
@@ -386,14 +398,29 @@ extern "C" int mpc_centerline_blocks(mpc_handle *h, const double *cl, int C, voi
     if (C == 0 || !cl) return MPC_OK;
     const DevCfg &c = h->dc;
     const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
-    if (NB > 64) return MPC_OK;           // the search keeps one bit per block: longer tables take the full scan
+    const bool blocks = NB <= 64;         // the block search keeps one bit per block: longer tables do without it
     const size_t bytes = sizeof(double) * 4 * (size_t)NB * (size_t)C;
-    if (bytes > h->cl_boxes_bytes) {
+    if (blocks && bytes > h->cl_boxes_bytes) {
         if (h->cl_boxes) { HIPCHK(hipFree(h->cl_boxes)); h->cl_boxes = nullptr; h->cl_boxes_bytes = 0; }
         if (hipMalloc((void **)&h->cl_boxes, bytes) != hipSuccess) return fail(MPC_E_ALLOC, "centerline block table hipMalloc failed");
         h->cl_boxes_bytes = bytes;
     }
-    hipLaunchKernelGGL(cl_blocks_kernel, grid_for(C * NB, 256), dim3(256), 0, (hipStream_t)stream, c, cl, C, h->cl_boxes);
+    if (!blocks && h->cl_boxes) { HIPCHK(hipFree(h->cl_boxes)); h->cl_boxes = nullptr; h->cl_boxes_bytes = 0; }
+    if (C > h->cl_grid_cap) {
+        if (h->cl_gmeta) { HIPCHK(hipFree(h->cl_gmeta)); h->cl_gmeta = nullptr; }
+        if (h->cl_gxy) { HIPCHK(hipFree(h->cl_gxy)); h->cl_gxy = nullptr; }
+        if (h->cl_gcells) { HIPCHK(hipFree(h->cl_gcells)); h->cl_gcells = nullptr; }
+        h->cl_grid_cap = 0;
+        if (hipMalloc((void **)&h->cl_gmeta, sizeof(double) * GRID_META * (size_t)C) != hipSuccess ||
+            hipMalloc((void **)&h->cl_gxy, sizeof(double) * 2 * (size_t)c.S * (size_t)C) != hipSuccess ||
+            hipMalloc((void **)&h->cl_gcells, sizeof(unsigned) * (size_t)GRID_CELLS * (size_t)C) != hipSuccess)
+            return fail(MPC_E_ALLOC, "centerline grid hipMalloc failed");
+        h->cl_grid_cap = C;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (blocks) hipLaunchKernelGGL(cl_blocks_kernel, grid_for(C * NB, 256), dim3(256), 0, s, c, cl, C, h->cl_boxes);
+    hipLaunchKernelGGL(cl_grid_meta_kernel, dim3((unsigned)C), dim3(64), 0, s, c, cl, C, h->cl_gmeta, h->cl_gxy);
+    hipLaunchKernelGGL(cl_grid_cells_kernel, dim3(GRID_CELLS / 256, C), dim3(256), 0, s, c, cl, C, h->cl_gmeta, h->cl_gcells);
     HIPCHK(hipGetLastError());
     h->cl_boxes_for = cl; h->cl_boxes_rows = C;
     return MPC_OK;
@@ -431,7 +458,7 @@ extern "C" int mpc_stage_errors(mpc_handle *h, int B, const double *pose, const 
     if (B == 0) return MPC_OK;
     if (!pose || !cl || !err) return fail(MPC_E_ARG, "mpc_stage_errors: null buffer");
     hipLaunchKernelGGL(errors_kernel, grid_for(B, 64), dim3(64), 0, (hipStream_t)stream, h->dc, B, pose, cl,
-                       cl_index, boxes_for(h, cl), err, idx);
+                       cl_index, near_for(h, cl), err, idx);
     HIPCHK(hipGetLastError());
     return MPC_OK;
 }
@@ -503,7 +530,7 @@ static int eval_cost_grad(mpc_handle *h, int B, const double *x0, const double *
     hipStream_t s = (hipStream_t)stream;
     // direct mode: the kernel reads and writes the caller's agent-major buffers in place
     Workspace w = h->ws;
-    w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.cl_boxes = boxes_for(h, cl);
+    w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.near = near_for(h, cl);
     w.arrive = h->arrive_adjoint ? h->arrive_buf : nullptr;
     if (w.arrive) HIPCHK(hipMemsetAsync(h->arrive_buf, 0, sizeof(int) * (size_t)(h->ws.St / 64 + 16), s));
     w.xe = const_cast<double *>(U); w.ge = grad ? grad : h->ws.ws_ge;
@@ -886,7 +913,7 @@ extern "C" int mpc_solve_batch(mpc_handle *h, int B, const double *x0, const dou
     hipStream_t s = (hipStream_t)stream;
     Workspace &w = h->ws;
     w.cl = cl; w.cl_index = cl_index; w.x0 = x0; w.xo = U; w.y = lambda; w.psi_direct = nullptr;
-    w.cl_boxes = boxes_for(h, cl);
+    w.near = near_for(h, cl);
     w.arrive = h->arrive_adjoint ? h->arrive_buf : nullptr;
     w.xe = w.ws_xe; w.ge = w.ws_ge; w.yhe = w.ws_yhe; w.Sig = w.ws_Sig;
     rc = run_solver(h, s); if (rc) return rc;
@@ -974,7 +1001,8 @@ extern "C" int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *laun
 extern "C" int mpc_set_nearest_blocks(mpc_handle *h, int on)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_set_nearest_blocks: null handle");
-    h->nearest_blocks = on != 0;
+    if (on < 0 || on > 2) return fail(MPC_E_ARG, "mpc_set_nearest_blocks: mode is 0 (full scan), 1 (block boxes) or 2 (grid)");
+    h->nearest_mode = on;
     return MPC_OK;
 }
 

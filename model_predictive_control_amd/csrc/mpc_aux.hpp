@@ -58,10 +58,81 @@ __global__ void cl_blocks_kernel(const DevCfg c, const double *__restrict__ cl, 
     q[0] = xlo; q[1] = xhi; q[2] = ylo; q[3] = yhi;
 }
 
-// a-4/a-5 standalone (boxes: the block boxes of the table, or null for the full scan)
+// placement of the nearest-point grid of every centerline row (one wave per row): the box of the
+// candidate points grown by 25 mean spacings, cells of half a spacing (larger if that takes more than
+// GRID_CELLS cells).  A row the grid cannot describe (non-finite or coincident points, S - 1 > 65535)
+// gets nx = ny = 0: every query is "outside" and takes the full scan.  Also writes the interleaved copy.
+__global__ void __launch_bounds__(64) cl_grid_meta_kernel(const DevCfg c, const double *__restrict__ cl, int C,
+                                                          double *__restrict__ meta, double *__restrict__ xy)
+{
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= C) return;
+    const int S = c.S, nc = S - 1;
+    const double *x = cl + (size_t)row * 2 * (size_t)S, *y = x + S;
+    double *q = xy + (size_t)row * 2 * (size_t)S;
+    for (int i = lane; i < S; i += 64) { q[2 * i] = x[i]; q[2 * i + 1] = y[i]; }
+    double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY, len = 0.0;
+    bool ok = true;
+    for (int i = lane; i < nc; i += 64) {
+        ok = ok && isfinite(x[i]) && isfinite(y[i]);
+        xlo = fmin(xlo, x[i]); xhi = fmax(xhi, x[i]); ylo = fmin(ylo, y[i]); yhi = fmax(yhi, y[i]);
+        if (i) len += sqrt((x[i] - x[i - 1]) * (x[i] - x[i - 1]) + (y[i] - y[i - 1]) * (y[i] - y[i - 1]));
+    }
+    for (int o = 32; o; o >>= 1) {
+        xlo = fmin(xlo, __shfl_xor(xlo, o)); xhi = fmax(xhi, __shfl_xor(xhi, o));
+        ylo = fmin(ylo, __shfl_xor(ylo, o)); yhi = fmax(yhi, __shfl_xor(yhi, o));
+        len += __shfl_xor(len, o);
+    }
+    ok = __ballot(!ok) == 0ull && nc >= 1 && nc <= 65535;
+    if (lane) return;
+    const double sp = nc > 1 ? len / (double)(nc - 1) : 1.0;
+    ok = ok && isfinite(sp) && sp > 0.0;
+    double *m = meta + (size_t)row * GRID_META;
+    for (int i = 0; i < GRID_META; i++) m[i] = 0.0;
+    if (!ok) return;
+    const double R = 25.0 * sp, W = (xhi - xlo) + 2.0 * R, H = (yhi - ylo) + 2.0 * R;
+    double cell = 0.5 * sp, nx = ceil(W / cell), ny = ceil(H / cell);
+    for (int it = 0; it < 64 && nx * ny > (double)GRID_CELLS; it++) {
+        cell *= 1.02 * sqrt(nx * ny / (double)GRID_CELLS);
+        nx = ceil(W / cell); ny = ceil(H / cell);
+    }
+    if (!(nx * ny <= (double)GRID_CELLS) || !isfinite(1.0 / cell)) return;
+    m[0] = xlo - R; m[1] = ylo - R; m[2] = 1.0 / cell; m[3] = nx; m[4] = ny; m[5] = cell;
+}
+
+// index range of one grid cell (one thread per cell): see nearest_index_grid
+__global__ void __launch_bounds__(256) cl_grid_cells_kernel(const DevCfg c, const double *__restrict__ cl, int C,
+                                                            const double *__restrict__ meta, unsigned *__restrict__ cells)
+{
+    const int row = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *m = meta + (size_t)row * GRID_META;
+    const int nx = (int)m[3], ny = (int)m[4];
+    if (t >= nx * ny) return;
+    const int S = c.S, nc = S - 1;
+    const double *x = cl + (size_t)row * 2 * (size_t)S, *y = x + S;
+    const double cell = m[5], e = 1e-6 * cell;
+    const int ix = t % nx, iy = t / nx;
+    const double rx0 = m[0] + ix * cell - e, rx1 = m[0] + (ix + 1) * cell + e;
+    const double ry0 = m[1] + iy * cell - e, ry1 = m[1] + (iy + 1) * cell + e;
+    double U = INFINITY;
+    for (int i = 0; i < nc; i++) {
+        const double ax = fmax(fabs(x[i] - rx0), fabs(x[i] - rx1)), ay = fmax(fabs(y[i] - ry0), fabs(y[i] - ry1));
+        U = fmin(U, ax * ax + ay * ay);
+    }
+    const double bound = U * (1.0 + 1e-9);
+    int lo = nc, hi = -1;
+    for (int i = 0; i < nc; i++) {
+        const double bx = fmax(fmax(rx0 - x[i], x[i] - rx1), 0.0), by = fmax(fmax(ry0 - y[i], y[i] - ry1), 0.0);
+        if (bx * bx + by * by <= bound) { lo = min(lo, i); hi = i; }
+    }
+    if (hi < 0) { lo = 0; hi = nc - 1; }      // (cannot happen: the point that attains U passes)
+    cells[(size_t)row * GRID_CELLS + t] = (unsigned)lo | ((unsigned)hi << 16);
+}
+
+// a-4/a-5 standalone (nt: the tables of the pruned searches, all null for the full scan)
 __global__ void errors_kernel(const DevCfg c, int B, const double *__restrict__ pose,
                               const double *__restrict__ cl, const int *__restrict__ cl_index,
-                              const double *__restrict__ boxes, double *__restrict__ err, int *__restrict__ idx_out)
+                              const NearTab nt, double *__restrict__ err, int *__restrict__ idx_out)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     // (no early return: the block search's loop is wave-uniform; lanes past the batch redo agent 0)
@@ -70,9 +141,7 @@ __global__ void errors_kernel(const DevCfg c, int B, const double *__restrict__ 
     const int row = cl_index ? cl_index[aa] : 0;
     const double *clp = cl + (size_t)row * 2 * (size_t)c.S;
     const double px = pose[(size_t)aa * 3], py = pose[(size_t)aa * 3 + 1], phi = pose[(size_t)aa * 3 + 2];
-    const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
-    const int idx = boxes ? nearest_index_blocks(c, clp, boxes + (size_t)row * NB * 4, px, py)
-                          : nearest_index(c, clp, px, py);
+    const int idx = nearest_lookup(c, clp, nt, row, px, py);
     if (!live) return;
     Geom g;
     load_geom(c, clp, idx, g);

@@ -847,6 +847,76 @@ MPC_DEV int nearest_index_blocks(const DevCfg &c, const double *__restrict__ cl,
     return idx;
 }
 
+// SURVEY 8f-2, second form: a uniform grid over the neighbourhood of a centerline row.  Every cell holds
+// the index range [lo, hi] that is GUARANTEED to contain the full scan's answer for any query point in
+// the cell: with U = min_j (largest squared distance from the cell to point j), the nearest point of any
+// query in the cell is at most U away, so it is among the points whose smallest squared distance to
+// the cell is <= U (cl_grid_cells_kernel adds a relative 1e-9 and grows the cell by 1e-6 of its size:
+// far more than the roundings of dist2 and of the cell lookup).  The first minimum of dist2 over
+// [lo, hi] is then the first minimum over all candidates -- the same index as nearest_index, bit for
+// bit, ties included -- and a lane looks at ~5-15 points instead of 98.  Points come from per-lane
+// 16-byte loads of the interleaved copy xy[S][2].  A wave with any lane outside the grid (or non-finite)
+// takes the full scan as a whole (uniform branch).  meta = [x0, y0, 1/cell, nx, ny, ...].
+constexpr int GRID_CELLS = 65536;   // cells per centerline row, at most
+constexpr int GRID_META = 8;        // doubles per row
+struct NearTab {
+    const double *boxes;            // [C][NB][4]        block boxes (nearest_index_blocks), or null
+    const double *gmeta;            // [C][GRID_META]    grid placement, or null
+    const unsigned *gcells;         // [C][GRID_CELLS]   lo | hi << 16
+    const double *gxy;              // [C][S][2]         interleaved points
+};
+
+// pt(i): point i of the row as a double2 (the interleaved copy in global memory, or a workgroup's copy of it in LDS)
+template <class Pt>
+MPC_DEV int nearest_index_grid(const DevCfg &c, const double *__restrict__ cl, const double *__restrict__ meta,
+                               const unsigned *__restrict__ cells, Pt pt, double px, double py)
+{
+#pragma clang fp contract(off)
+    const double fx = (px - meta[0]) * meta[2], fy = (py - meta[1]) * meta[2];
+    const bool in = fx >= 0.0 && fx < meta[3] && fy >= 0.0 && fy < meta[4];
+    if (__ballot(!in) != 0ull) return nearest_index(c, cl, px, py);
+    const unsigned r = cells[(int)fy * (int)meta[3] + (int)fx];
+    const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+    const double2 p0 = pt(lo);
+    double best = dist2(p0.x, p0.y, px, py);
+    int idx = lo;
+    // four points per trip (their loads are in flight together); a lane whose range has ended repeats
+    // its last point, which the strict "<" ignores
+    for (int t = lo + 1; __ballot(t <= hi) != 0ull; t += 4) {
+        const int i0 = min(t, hi), i1 = min(t + 1, hi), i2 = min(t + 2, hi), i3 = min(t + 3, hi);
+        const double2 q0 = pt(i0), q1 = pt(i1), q2 = pt(i2), q3 = pt(i3);
+        const double d0 = dist2(q0.x, q0.y, px, py), d1 = dist2(q1.x, q1.y, px, py);
+        const double d2 = dist2(q2.x, q2.y, px, py), d3 = dist2(q3.x, q3.y, px, py);
+        const bool l01 = d1 < d0, l23 = d3 < d2;
+        const double m01 = l01 ? d1 : d0, m23 = l23 ? d3 : d2;
+        const int i01 = l01 ? i1 : i0, i23 = l23 ? i3 : i2;
+        const bool lq = m23 < m01;
+        const double mq = lq ? m23 : m01;
+        const int iq = lq ? i23 : i01;
+        const bool lt = mq < best;
+        best = lt ? mq : best;
+        idx = lt ? iq : idx;
+    }
+    return idx;
+}
+
+// the search the tables of `nt` allow for centerline row `row` (all of them return nearest_index's answer)
+MPC_DEV int nearest_lookup(const DevCfg &c, const double *__restrict__ clp, const NearTab &nt, int row,
+                           double px, double py)
+{
+    if (nt.gmeta) {
+        const double *meta = nt.gmeta + (size_t)row * GRID_META;
+        const unsigned *cells = nt.gcells + (size_t)row * GRID_CELLS;
+        const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(nt.gxy + (size_t)row * 2 * (size_t)c.S);
+        return nearest_index_grid(c, clp, meta, cells, [=](int i) { return gp[i]; }, px, py);
+    }
+    if (nt.boxes) {
+        const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
+        return nearest_index_blocks(c, clp, nt.boxes + (size_t)row * NB * 4, px, py);
+    }
+    return nearest_index(c, clp, px, py);
+}
+
 struct Geom { double nx_, ny_, px_, py_, qx_, qy_; }; // nearest, previous, next
 
 MPC_DEV void load_geom(const DevCfg &c, const double *__restrict__ cl, int idx, Geom &g)
@@ -856,6 +926,13 @@ MPC_DEV void load_geom(const DevCfg &c, const double *__restrict__ cl, int idx, 
     g.nx_ = cl[idx]; g.ny_ = cl[S + idx];
     g.px_ = cl[ip]; g.py_ = cl[S + ip];
     g.qx_ = cl[idx + 1]; g.qy_ = cl[S + idx + 1];
+}
+
+// the same three points out of an interleaved copy of the row
+MPC_DEV void load_geom_xy(const double2 *xy, int idx, Geom &g)
+{
+    const double2 n = xy[idx], p = xy[idx > 0 ? idx - 1 : 0], q = xy[idx + 1];
+    g.nx_ = n.x; g.ny_ = n.y; g.px_ = p.x; g.py_ = p.y; g.qx_ = q.x; g.qy_ = q.y;
 }
 
 // car_dynamics.py:168-172 with the three possible lowerings of np.mod on an SX

@@ -366,16 +366,17 @@ rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 // per (slot, stage) record written for gradient requests: dL/dx (NX), dL/du (2), T (NX x NX)
 template <int MODEL> struct JacRec { static constexpr int SIZE = ModelDim<MODEL>::NX * (ModelDim<MODEL>::NX + 1) + 2; };
 
-// block boxes of centerline row `row` (null when none were prepared: full scan)
-__device__ __forceinline__ const double *box_row(const DevCfg &c, const Workspace &w, int row)
+// the nearest centerline point of (px, py) and its two neighbours.  row: the centerline row of clp (the
+// pruned searches keep tables per row) -- the same index whichever search runs
+__device__ __forceinline__ void stage_geom(const DevCfg &c, const Workspace &w, const double *__restrict__ clp, int row,
+                                           double px, double py, Geom &g)
 {
-    const int NB = (c.S - 1 + NEAR_BLK - 1) / NEAR_BLK;
-    return w.cl_boxes ? w.cl_boxes + (size_t)row * NB * 4 : nullptr;
+    load_geom(c, clp, nearest_lookup(c, clp, w.near, row, px, py), g);
 }
 
-// K1b for one (request, stage): nearest point, stage cost, ALM terms and -- for gradient requests --
+// K1b for one (request, stage): [nearest point: stage_geom], stage cost, ALM terms and -- for gradient requests --
 // the stage's cost gradient and transition sensitivities.  `put(f, v)` stores field f of the stage
-// record: dL/dx (NX), dL/du (2), T (NX x NX), and field JS = the stage cost.  One body for the
+// record: dL/dx (NX), dL/du (2), and field JS = the stage cost (T (NX x NX): stage_sens_record).  One body for the
 // two-kernel path (records in the slot-indexed scratch), the fused kernel and the persistent solo kernel
 // (records in LDS).  The cost arithmetic is written with fixed roundings (no contraction, explicit
 // fma): the same request must give the same bits whichever kernel this is inlined into.
@@ -383,13 +384,9 @@ template <int MODEL, class Put>
 __device__ __forceinline__ void stage_record(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g,
                                              int k, const double (&xs)[ModelDim<MODEL>::NX],
                                              const double (&xe)[ModelDim<MODEL>::NX], double d, double dl,
-                                             const double *__restrict__ clp, const double *__restrict__ bxp, Put put)
+                                             const Geom &g, Put put)
 {
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
-    // bxp: the block boxes of this centerline row (null: look at every point) -- same index either way
-    const int idx = bxp ? nearest_index_blocks(c, clp, bxp, xe[0], xe[1]) : nearest_index(c, clp, xe[0], xe[1]);
-    Geom g;
-    load_geom(c, clp, idx, g);
     double xb[NX], ub[2] = {0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < NX; i++) xb[i] = 0.0;
@@ -418,19 +415,29 @@ __device__ __forceinline__ void stage_record(const DevCfg &c, const Workspace &w
     }
     put(JS, L);
     if (is_g) {
-        StageInput<MODEL> u;
-        prep_input(c, d, dl, u);
-        double T[NX][NX];
-        stage_tangents<MODEL>(c, u, xs, T);
 #pragma unroll
         for (int i = 0; i < NX; i++) put(i, xb[i]);
         put(NX, ub[0]);
         put(NX + 1, ub[1]);
+    }
+}
+
+// the transition sensitivities of a gradient request's stage (fields NX + 2 .. JS - 1 of its record).
+// Called BEFORE the cost part: the sixteen values leave for memory while the nearest-point search and
+// the cost are computed, and neither part holds the other's registers.
+template <int MODEL, class Put>
+__device__ __forceinline__ void stage_sens_record(const DevCfg &c, const double (&xs)[ModelDim<MODEL>::NX],
+                                                  double d, double dl, Put put)
+{
+    constexpr int NX = ModelDim<MODEL>::NX;
+    StageInput<MODEL> u;
+    prep_input(c, d, dl, u);
+    double T[NX][NX];
+    stage_tangents<MODEL>(c, u, xs, T);
 #pragma unroll
-        for (int dd = 0; dd < NX; dd++) {
+    for (int dd = 0; dd < NX; dd++) {
 #pragma unroll
-            for (int i = 0; i < NX; i++) put(NX + 2 + dd * NX + i, T[dd][i]);
-        }
+        for (int i = 0; i < NX; i++) put(NX + 2 + dd * NX + i, T[dd][i]);
     }
 }
 
@@ -484,8 +491,14 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
 // its counter form).  No wave waits for another one.  The adjoint launch and its place in a round's
 // chain of dependent launches disappear; the arithmetic is adjoint_rec either way: same bits.
 // (kinematic: held to 168 registers = three waves per SIMD, 144 B of scratch per lane: K1b -3.6 %)
+#ifndef MPC_K1B_WAVES
+#define MPC_K1B_WAVES 3
+#endif
+// (tried: the gradient blocks and the cost blocks by kernels of their own -- the cost-only variant needs 55
+// registers and runs eight waves per SIMD, 13 us per launch against 75 us for the gradient blocks -- but
+// the pair of launches is slower than the one: 180.2 vs 175.6 ms per solve)
 template <int MODEL, bool SHARED_CL>
-__global__ void __launch_bounds__(64, (MODEL == KIN ? 3 : 1))
+__global__ void __launch_bounds__(64, (MODEL == KIN ? MPC_K1B_WAVES : 1))
 stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
              int nblk_max)
 {
@@ -497,6 +510,15 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
     const int uslot = sb * 64 + threadIdx.x;
     const int raw = w.agent_of[uslot];
     const bool arr = w.arrive != nullptr;                // uniform
+    // grid search on a shared centerline: the wave keeps the row's points (1.6 KB) in LDS, so that the
+    // candidate points and the three geometry points after them are LDS reads, not two more trips to L2
+    extern __shared__ double2 s_xy[];
+    const bool lds_xy = SHARED_CL && w.near.gmeta != nullptr;                      // uniform; the host sizes the LDS
+    if (lds_xy) {
+        const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(w.near.gxy);
+        for (int j = threadIdx.x; j < c.S; j += 64) s_xy[j] = gp[j];
+        __builtin_amdgcn_wave_barrier();                                           // (all 64 lanes are still here)
+    }
     if (raw < 0 && !arr) return;
     const int a = raw & AGENT_MASK;
     const bool ch2 = (raw & CH2_BIT) != 0;   // speculative channel: only the gradient is kept
@@ -512,12 +534,20 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
         const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
         double *const jr = w.jac + (size_t)k * JS * St + uslot;
         double *const sl = w.stage_L + (size_t)k * St + uslot;
-        stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, box_row(c, w, SHARED_CL ? 0 : w.cl_index[a]),
-                            [=](int f, double v) {
-                                double *p = f == JS ? sl : jr + (size_t)f * St;
-                                if (arr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                else *p = v;
-                            });
+        const auto put = [=](int f, double v) {
+            double *p = f == JS ? sl : jr + (size_t)f * St;
+            if (arr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *p = v;
+        };
+        if (is_g) stage_sens_record<MODEL>(c, xs, d, dl, put);
+        Geom g;
+        if (lds_xy) {
+            const int idx = nearest_index_grid(c, clp, w.near.gmeta, w.near.gcells, [=](int i) { return s_xy[i]; }, xe[0], xe[1]);
+            load_geom_xy(s_xy, idx, g);
+        } else {
+            stage_geom(c, w, clp, SHARED_CL ? 0 : w.cl_index[a], xe[0], xe[1], g);
+        }
+        stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, g, put);
     }
     if (!arr) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's record stores have left
@@ -591,8 +621,11 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
             const double d = w.useq[(size_t)(2 * k) * St + uslot], dl = w.useq[(size_t)(2 * k + 1) * St + uslot];
             const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
             double *const r = s_rec + k * SPB + j;
-            stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, clp, box_row(c, w, SHARED_CL ? 0 : w.cl_index[a]),
-                                [=](int f, double v) { r[(size_t)f * NS] = v; });
+            const auto put = [=](int f, double v) { r[(size_t)f * NS] = v; };
+            if (is_g) stage_sens_record<MODEL>(c, xs, d, dl, put);
+            Geom g;
+            stage_geom(c, w, clp, SHARED_CL ? 0 : w.cl_index[a], xe[0], xe[1], g);
+            stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, g, put);
         }
     }
     __syncthreads();

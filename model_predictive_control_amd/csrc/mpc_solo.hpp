@@ -99,8 +99,11 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
         for (int i = 0; i < NX; i++) { xs[i] = tj[hl * NX + i]; xe[i] = tj[(hl + 1) * NX + i]; }
         const double *__restrict__ clp = w.cl_index ? w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S : w.cl;
         double *const r = rc + hl;
-        stage_record<MODEL>(c, w, a, ch2, is_g, hl, xs, xe, d, dl, clp, box_row(c, w, w.cl_index ? w.cl_index[a] : 0),
-                            [=](int f, double v) { r[f * N] = v; });
+        const auto put = [=](int f, double v) { r[f * N] = v; };
+        if (is_g) stage_sens_record<MODEL>(c, xs, d, dl, put);
+        Geom g;
+        stage_geom(c, w, clp, w.cl_index ? w.cl_index[a] : 0, xe[0], xe[1], g);
+        stage_record<MODEL>(c, w, a, ch2, is_g, hl, xs, xe, d, dl, g, put);
     }
     __builtin_amdgcn_wave_barrier();
     if (hl == 0 && live) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rc[f * N + k]; });

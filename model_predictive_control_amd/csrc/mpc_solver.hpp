@@ -60,7 +60,7 @@ struct Workspace {
     int *arrive;                                   // [St / 64]      stage blocks done per slot block (K1c inside K1b), or null
     const double *cl;                              // [C][2S]
     const int *cl_index;                           // [B] or null
-    const double *cl_boxes;                        // [C][NB][4] block bounding boxes of the centerline rows, or null
+    NearTab near;                                  // tables of the pruned nearest-point searches (all null: full scan)
     double *psi_direct;                            // direct-mode K1 output (standalone evaluation)
     double *ws_xe, *ws_ge, *ws_yhe, *ws_Sig;       // the workspace's own rows (xe/ge/yhe/Sig may alias caller buffers)
     int B, Bp;                                     // agents of this view, rounded up to 64

@@ -39,7 +39,8 @@ class BatchedMPC:
         _lib.check(self.lib.mpc_create(C.byref(cfg), idx, C.byref(h)))
         self._h = h
         import os
-        self._nearest_blocks = "MPC_NEAREST_BLOCKS" in os.environ
+        # nearest-point search of K1b: 2 grid of index ranges (default), 1 block boxes, 0 the full scan
+        self._nearest_blocks = 0 if "MPC_NEAREST_SCAN" in os.environ else 1 if "MPC_NEAREST_BLOCKS" in os.environ else 2
 
     def close(self):
         if getattr(self, "_h", None):
@@ -81,8 +82,8 @@ class BatchedMPC:
             if B and (int(cl_index.min()) < 0 or int(cl_index.max()) >= cl.shape[0]):
                 raise ValueError("cl_index out of range")
         if self._nearest_blocks:
-            # f-2: block boxes of this table for the pruned nearest-point search (a few threads; redone
-            # on every call because the caller may have changed the table in place)
+            # f-2: the tables of the pruned nearest-point searches for this centerline table (three small
+            # kernels; redone on every call because the caller may have changed the table in place)
             _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
         return cl
 
@@ -243,9 +244,10 @@ class BatchedMPC:
         _lib.check(self.lib.mpc_set_groups(self._h, int(groups)))
 
     def set_nearest_blocks(self, on=True):
-        """Block-pruned nearest-point search or (default) the full 98-candidate scan: same index."""
-        self._nearest_blocks = bool(on)
-        _lib.check(self.lib.mpc_set_nearest_blocks(self._h, int(bool(on))))
+        """Nearest-point search of K1b: 0 / False the full 98-candidate scan, 1 / True the block-pruned
+        search, 2 the grid of index ranges -- the same index whichever runs."""
+        self._nearest_blocks = int(on)
+        _lib.check(self.lib.mpc_set_nearest_blocks(self._h, int(on)))
 
     def set_solo_max(self, max_requests):
         """Requests per round up to which a group finishes in the persistent wave-per-agent kernel (0 = off)."""

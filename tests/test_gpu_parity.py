@@ -111,12 +111,14 @@ def test_tracking_errors_match_oracle_and_road_py(dev, O, ref_golden):
     assert np.allclose(err[ok, 1], ref_golden["road_err"][ok, 1], rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("S", [100, 6, 37, 130])
-def test_block_pruned_nearest_point_is_exact(dev, O, S):
-    """f-2 (car_dynamics.py:185-190): the block-pruned search returns the reference's argmin -- first
-    index of the minimum over the points 0 .. S-2 -- bit-exactly: against the full scan and against the
-    oracle, on the straight line, the circle and the ten Bezier lane-change rows; exact ties (a pose
-    midway between two points), index-0 wins, the excluded last point, far-away and non-finite poses,
+def test_block_pruned_nearest_point_is_exact(dev, O, S, mode):
+    """f-2 (car_dynamics.py:185-190): the pruned searches (mode 1: block boxes, mode 2: grid of index
+    ranges) return the reference's argmin -- first index of the minimum over the points 0 .. S-2 --
+    bit-exactly: against the full scan and against the oracle, on the straight line, the circle and the
+    ten Bezier lane-change rows; exact ties (a pose midway between two points), index-0 wins, the
+    excluded last point, far-away and non-finite poses, poses all over the grid and beyond its edge,
     block counts that do not divide S - 1."""
     from model_predictive_control_amd import bezier_curves as bc
     cfg, ocfg = both(O, 1, 12, S=S)
@@ -130,15 +132,20 @@ def test_block_pruned_nearest_point_is_exact(dev, O, S):
     tab = np.stack(rows)
     C = tab.shape[0]
     rng = np.random.default_rng(S)
-    per = 400
+    per, near = 640, 400
     ci = np.repeat(np.arange(C), per).astype(np.int32)
     B = ci.size
     pts = np.empty((B, 2))
     for r in range(C):
         x, y = tab[r, :S], tab[r, S:]
-        k = rng.integers(0, S, per)
-        pts[r * per:(r + 1) * per, 0] = x[k] + rng.normal(0, 0.3, per)
-        pts[r * per:(r + 1) * per, 1] = y[k] + rng.normal(0, 0.3, per)
+        k = rng.integers(0, S, near)
+        pts[r * per:r * per + near, 0] = x[k] + rng.normal(0, 0.3, near)
+        pts[r * per:r * per + near, 1] = y[k] + rng.normal(0, 0.3, near)
+        # all over the neighbourhood the grid covers (25 mean spacings around the row) and a little beyond
+        sp = np.hypot(np.diff(x[:S - 1]), np.diff(y[:S - 1])).mean() if S > 2 else 1.0
+        m = 30 * sp
+        pts[r * per + near:(r + 1) * per, 0] = rng.uniform(x.min() - m, x.max() + m, per - near)
+        pts[r * per + near:(r + 1) * per, 1] = rng.uniform(y.min() - m, y.max() + m, per - near)
     g0 = 2 * per                                              # the integer grid row: ties and boundary cases
     ties = np.arange(0, min(S - 1, 60)) + 0.5
     pts[g0:g0 + ties.size] = np.stack([ties, np.zeros_like(ties)], 1)                  # midway: lower index wins
@@ -146,7 +153,7 @@ def test_block_pruned_nearest_point_is_exact(dev, O, S):
     pts[g0 + 63] = [3.0, 1e6]; pts[g0 + 64] = [np.nan, 0.0]; pts[g0 + 65] = [np.inf, 1.0]
     pose = np.concatenate([pts, np.zeros((B, 1))], 1)
     P, TAB, CI = T(pose, dev), T(tab, dev), T(ci, dev, torch.int32)
-    eng.set_nearest_blocks(True)
+    eng.set_nearest_blocks(mode)
     eb, ib = eng.stage_errors(P, TAB, CI)
     eng.set_nearest_blocks(False)
     es, isc = eng.stage_errors(P, TAB, CI)
@@ -161,7 +168,7 @@ def test_block_pruned_nearest_point_is_exact(dev, O, S):
     N = 12
     X0 = synthetic_states(1, 96, seed=2); U = np.tile([0.8, 0.02], (96, N))
     ci2 = (np.arange(96) % C).astype(np.int32)
-    eng.set_nearest_blocks(True)
+    eng.set_nearest_blocks(mode)
     p1, g1, _ = eng.eval_cost_grad(T(X0, dev), TAB, T(U, dev), cl_index=T(ci2, dev, torch.int32))
     eng.set_nearest_blocks(False)
     p2, g2, _ = eng.eval_cost_grad(T(X0, dev), TAB, T(U, dev), cl_index=T(ci2, dev, torch.int32))
