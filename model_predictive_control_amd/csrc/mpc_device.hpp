@@ -756,6 +756,108 @@ MPC_DEV void stage_tangents(const DevCfg &c, const StageInput<MODEL> &u,
     for (int i = 3; i < NX; i++) T[0][i] = 0.0;
 }
 
+// The kinematic stage with nfe = 4 inside the fast range (kin4_in_range): the sensitivities written out
+// for this model instead of four generic Jacobian-vector products per RK4 step.  Speed and heading do not
+// see the position, the speed does not see the steering, and the position only collects increments,
+// so per RK4 step a direction needs: its speed chain (4 values; none for the steering direction), its
+// heading chain (4 values), and the increments d(kx_i, ky_i) = (c_i dv_i - ky_i dtheta_i,
+// s_i dv_i + kx_i dtheta_i).  Same stage values (kin_rk) and sin/cos pairs (one reduction + three
+// rotations) as the forward rollout.  Far fewer live values than the generic form (no Lin records, no k
+// arrays, no structural zeros): K1b's gradient blocks fit three waves per SIMD without spilling.
+// xe is the stage's end state AS THE ROLLOUT COMPUTED IT: the heading direction is the displacement
+// (xe - xs) turned by 90 degrees (see stage_tangents).  Fixed roundings throughout.
+MPC_DEV void stage_tangents_kin4(const DevCfg &c, const StageInput<KIN> &u, const double (&xs)[4],
+                                 const double (&xe)[4], double (&T)[4][4])
+{
+#pragma clang fp contract(off)
+    const double h = c.h, hh = 0.5 * h, h6 = h / 6.0, nf = -c.friction;
+    const double A = c.accel * u.mk0;           // d vdot / d drive
+    const double Cd = u.dbeta * u.mk1;          // d (phi + beta) / d delta
+    const double Bd = u.cb_lr * Cd;             // d (phidot / v) / d delta
+    double ph = xs[2], v = xs[3];
+    double ax = 0.0, ay = 0.0, ap = 0.0, av = 1.0;   // direction: speed
+    double bx = 0.0, by = 0.0, bp = 0.0, bv = 0.0;   // direction: drive
+    double ex = 0.0, ey = 0.0, ep = 0.0;             // direction: steering (its speed tangent is zero)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        KinRK k;
+        kin_rk(c, u, v, k);
+        const SinCos a0 = lean_sincos(ph + u.beta);
+        const SinCos a1 = rotate_sincos(a0, hh * k.kp1), a2 = rotate_sincos(a0, hh * k.kp2), a3 = rotate_sincos(a0, h * k.kp3);
+        const double k1x = k.v1 * a0.c, k2x = k.v2 * a1.c, k3x = k.v3 * a2.c, k4x = k.v4 * a3.c;
+        const double k1y = k.v1 * a0.s, k2y = k.v2 * a1.s, k3y = k.v3 * a2.s, k4y = k.v4 * a3.s;
+        {   // speed direction
+            const double d1 = av, e1 = nf * d1, d2 = fma(hh, e1, av), e2 = nf * d2, d3 = fma(hh, e2, av), e3 = nf * d3,
+                         d4 = fma(h, e3, av), e4 = nf * d4;
+            const double p1 = d1 * u.sb_lr, p2 = d2 * u.sb_lr, p3 = d3 * u.sb_lr, p4 = d4 * u.sb_lr;
+            const double f1 = ap, f2 = fma(hh, p1, ap), f3 = fma(hh, p2, ap), f4 = fma(h, p3, ap);
+            const double g1x = fma(-k1y, f1, a0.c * d1), g2x = fma(-k2y, f2, a1.c * d2), g3x = fma(-k3y, f3, a2.c * d3),
+                         g4x = fma(-k4y, f4, a3.c * d4);
+            const double g1y = fma(k1x, f1, a0.s * d1), g2y = fma(k2x, f2, a1.s * d2), g3y = fma(k3x, f3, a2.s * d3),
+                         g4y = fma(k4x, f4, a3.s * d4);
+            ax = fma(h6, fma(2.0, g3x, fma(2.0, g2x, g1x)) + g4x, ax);
+            ay = fma(h6, fma(2.0, g3y, fma(2.0, g2y, g1y)) + g4y, ay);
+            ap = fma(h6, fma(2.0, p3, fma(2.0, p2, p1)) + p4, ap);
+            av = fma(h6, fma(2.0, e3, fma(2.0, e2, e1)) + e4, av);
+        }
+        {   // drive direction
+            const double d1 = bv, e1 = fma(nf, d1, A), d2 = fma(hh, e1, bv), e2 = fma(nf, d2, A), d3 = fma(hh, e2, bv),
+                         e3 = fma(nf, d3, A), d4 = fma(h, e3, bv), e4 = fma(nf, d4, A);
+            const double p1 = d1 * u.sb_lr, p2 = d2 * u.sb_lr, p3 = d3 * u.sb_lr, p4 = d4 * u.sb_lr;
+            const double f1 = bp, f2 = fma(hh, p1, bp), f3 = fma(hh, p2, bp), f4 = fma(h, p3, bp);
+            const double g1x = fma(-k1y, f1, a0.c * d1), g2x = fma(-k2y, f2, a1.c * d2), g3x = fma(-k3y, f3, a2.c * d3),
+                         g4x = fma(-k4y, f4, a3.c * d4);
+            const double g1y = fma(k1x, f1, a0.s * d1), g2y = fma(k2x, f2, a1.s * d2), g3y = fma(k3x, f3, a2.s * d3),
+                         g4y = fma(k4x, f4, a3.s * d4);
+            bx = fma(h6, fma(2.0, g3x, fma(2.0, g2x, g1x)) + g4x, bx);
+            by = fma(h6, fma(2.0, g3y, fma(2.0, g2y, g1y)) + g4y, by);
+            bp = fma(h6, fma(2.0, p3, fma(2.0, p2, p1)) + p4, bp);
+            bv = fma(h6, fma(2.0, e3, fma(2.0, e2, e1)) + e4, bv);
+        }
+        {   // steering direction
+            const double p1 = k.v1 * Bd, p2 = k.v2 * Bd, p3 = k.v3 * Bd, p4 = k.v4 * Bd;
+            const double f1 = ep + Cd, f2 = fma(hh, p1, ep) + Cd, f3 = fma(hh, p2, ep) + Cd, f4 = fma(h, p3, ep) + Cd;
+            const double sx = fma(2.0, k3y * f3, fma(2.0, k2y * f2, k1y * f1)) + k4y * f4;
+            const double sy = fma(2.0, k3x * f3, fma(2.0, k2x * f2, k1x * f1)) + k4x * f4;
+            ex = fma(-h6, sx, ex);
+            ey = fma(h6, sy, ey);
+            ep = fma(h6, fma(2.0, p3, fma(2.0, p2, p1)) + p4, ep);
+        }
+        kin_next(c, k, ph, v);
+        __builtin_amdgcn_sched_barrier(0);      // one RK4 step's values at a time (see stage_forward_kin4)
+    }
+    T[0][0] = -(xe[1] - xs[1]); T[0][1] = xe[0] - xs[0]; T[0][2] = 1.0; T[0][3] = 0.0;
+    T[1][0] = ax; T[1][1] = ay; T[1][2] = ap; T[1][3] = av;
+    T[2][0] = bx; T[2][1] = by; T[2][2] = bp; T[2][3] = bv;
+    T[3][0] = ex; T[3][1] = ey; T[3][2] = ep; T[3][3] = 0.0;
+}
+
+// stage_tangents with the rollout's end state at hand: the kinematic model takes the form above when it
+// applies (a lane's result never depends on the other lanes of its wave: a lane outside the fast range
+// keeps the generic form while its neighbours keep theirs)
+template <int MODEL>
+MPC_DEV void stage_tangents_at(const DevCfg &c, const StageInput<MODEL> &u, const double (&xs)[ModelDim<MODEL>::NX],
+                               const double (&xe)[ModelDim<MODEL>::NX],
+                               double (&T)[ModelDim<MODEL>::NX][ModelDim<MODEL>::NX])
+{
+    if constexpr (MODEL == KIN) {
+        if (c.nfe == 4) {
+            const bool ok = kin4_in_range(c, u, xs);
+            if (__builtin_expect(__ballot(!ok) == 0ull, 1)) { stage_tangents_kin4(c, u, xs, xe, T); return; }
+            double xa[4] = {xs[0], xs[1], ok ? xs[2] : 0.0, ok ? xs[3] : 0.0}, Ta[4][4];
+            stage_tangents_kin4(c, u, xa, xe, Ta);
+            stage_tangents<MODEL>(c, u, xs, T);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) T[d][i] = ok ? Ta[d][i] : T[d][i];
+            }
+            return;
+        }
+    }
+    stage_tangents<MODEL>(c, u, xs, T);
+}
+
 // ---------------------------------------------------------------------------------- tracking
 // car_dynamics.py:174-192: start at point 0, candidates 1..S-2, strict <.  Squared distances are
 // compared (sqrt is monotone).  cl is the flat row [x_0..x_{S-1}, y_0..y_{S-1}].

@@ -427,13 +427,13 @@ __device__ __forceinline__ void stage_record(const DevCfg &c, const Workspace &w
 // the cost are computed, and neither part holds the other's registers.
 template <int MODEL, class Put>
 __device__ __forceinline__ void stage_sens_record(const DevCfg &c, const double (&xs)[ModelDim<MODEL>::NX],
-                                                  double d, double dl, Put put)
+                                                  const double (&xe)[ModelDim<MODEL>::NX], double d, double dl, Put put)
 {
     constexpr int NX = ModelDim<MODEL>::NX;
     StageInput<MODEL> u;
     prep_input(c, d, dl, u);
     double T[NX][NX];
-    stage_tangents<MODEL>(c, u, xs, T);
+    stage_tangents_at<MODEL>(c, u, xs, xe, T);
 #pragma unroll
     for (int dd = 0; dd < NX; dd++) {
 #pragma unroll
@@ -539,7 +539,7 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
             if (arr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else *p = v;
         };
-        if (is_g) stage_sens_record<MODEL>(c, xs, d, dl, put);
+        if (is_g) stage_sens_record<MODEL>(c, xs, xe, d, dl, put);
         Geom g;
         if (lds_xy) {
             const int idx = nearest_index_grid(c, clp, w.near.gmeta, w.near.gcells, [=](int i) { return s_xy[i]; }, xe[0], xe[1]);
@@ -622,7 +622,7 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
             const double *__restrict__ clp = SHARED_CL ? w.cl : w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S;
             double *const r = s_rec + k * SPB + j;
             const auto put = [=](int f, double v) { r[(size_t)f * NS] = v; };
-            if (is_g) stage_sens_record<MODEL>(c, xs, d, dl, put);
+            if (is_g) stage_sens_record<MODEL>(c, xs, xe, d, dl, put);
             Geom g;
             stage_geom(c, w, clp, SHARED_CL ? 0 : w.cl_index[a], xe[0], xe[1], g);
             stage_record<MODEL>(c, w, a, ch2, is_g, k, xs, xe, d, dl, g, put);

@@ -100,7 +100,7 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
         const double *__restrict__ clp = w.cl_index ? w.cl + (size_t)w.cl_index[a] * 2 * (size_t)c.S : w.cl;
         double *const r = rc + hl;
         const auto put = [=](int f, double v) { r[f * N] = v; };
-        if (is_g) stage_sens_record<MODEL>(c, xs, d, dl, put);
+        if (is_g) stage_sens_record<MODEL>(c, xs, xe, d, dl, put);
         Geom g;
         stage_geom(c, w, clp, w.cl_index ? w.cl_index[a] : 0, xe[0], xe[1], g);
         stage_record<MODEL>(c, w, a, ch2, is_g, hl, xs, xe, d, dl, g, put);
