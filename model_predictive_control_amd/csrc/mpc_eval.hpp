@@ -99,7 +99,10 @@ rollout_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
 // the chain length: a round with all agents active gives the thread-per-request kernel 1.4 waves per
 // SIMD (its makespan is that of the SIMDs holding two), a sub-batch group a third of that.  The same
 // helper functions with fixed roundings as rollout_kernel<KIN> and the wave-per-request kernel: same bits.
-__global__ void __launch_bounds__(64)
+#ifndef MPC_K1A_WAVES
+#define MPC_K1A_WAVES 3
+#endif
+__global__ void __launch_bounds__(64, MPC_K1A_WAVES)
 rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
                     const int *__restrict__ counts, int nG_imm, int nC_imm)
 {
@@ -142,11 +145,11 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
         w.trajx[(size_t)(k * 4 + 2 * half + 1) * St + uslot] = half ? x[3] : x[1];
     };
     put(0);
-    for (int k = 0; k < N; k++) {
+    // the stage inputs (beta, sin(beta) / lr, ...: a division chain of ~100 instructions) are prepared
+    // two stages at a time, stage k + half by lane `half`, and handed to the partner by DPP
+    auto stage = [&](int k, const StageInput<KIN> &u) {
         const double d = urow[2 * k], dl = urow[2 * k + 1];
         w.useq[(size_t)(2 * k + half) * St + uslot] = half ? dl : d;
-        StageInput<KIN> u;
-        prep_input(c, d, dl, u);
         const bool ok = kin4_in_range(c, u, x);
         if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
             // heading / speed at the start of the four RK4 steps, and the stage values of each
@@ -177,8 +180,26 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
             stage_forward<KIN>(c, u, x);                 // some lane is out of range: the thread-per-request code
         }
         put(k + 1);
+    };
+    for (int k = 0; k < N; k += 2) {
+        const int km = min(k + half, N - 1);
+        StageInput<KIN> um, up;
+        prep_input(c, urow[2 * km], urow[2 * km + 1], um);
+        up.ad = dpp_xchg<0xB1>(um.ad); up.beta = dpp_xchg<0xB1>(um.beta);
+        up.sb_lr = dpp_xchg<0xB1>(um.sb_lr); up.cb_lr = dpp_xchg<0xB1>(um.cb_lr);
+        up.dbeta = dpp_xchg<0xB1>(um.dbeta); up.mk0 = dpp_xchg<0xB1>(um.mk0); up.mk1 = dpp_xchg<0xB1>(um.mk1);
+        StageInput<KIN> ua, ub;
+        ua.ad = half ? up.ad : um.ad; ua.beta = half ? up.beta : um.beta; ua.sb_lr = half ? up.sb_lr : um.sb_lr;
+        ua.cb_lr = half ? up.cb_lr : um.cb_lr; ua.dbeta = half ? up.dbeta : um.dbeta;
+        ua.mk0 = half ? up.mk0 : um.mk0; ua.mk1 = half ? up.mk1 : um.mk1;
+        ub.ad = half ? um.ad : up.ad; ub.beta = half ? um.beta : up.beta; ub.sb_lr = half ? um.sb_lr : up.sb_lr;
+        ub.cb_lr = half ? um.cb_lr : up.cb_lr; ub.dbeta = half ? um.dbeta : up.dbeta;
+        ub.mk0 = half ? um.mk0 : up.mk0; ub.mk1 = half ? um.mk1 : up.mk1;
+        stage(k, ua);
+        if (k + 1 < N) stage(k + 1, ub);
     }
 }
+
 
 // K1a of the Pacejka model by FOUR lanes per request (rhs_quad): a workgroup of 64 threads takes 16
 // requests.  The rollout is one serial chain of 16 N RHS evaluations whatever the batch, and a batch of
