@@ -443,6 +443,17 @@ __device__ __forceinline__ void stage_record(const DevCfg &c, const Workspace &w
     }
 }
 
+// Entries of the sensitivity block that are the same constant for every stage and request: the heading
+// direction's row is [-dy, dx, 1, 0, ..] (stage_tangents), and the kinematic speed does not see the
+// steering.  They are neither stored by K1b nor read by K1c (3 of the 22 record fields of the kinematic
+// model, 4 of 44 of the Pacejka model; K1c is bound by that traffic); the recursion multiplies by the
+// literal instead -- same bits as multiplying by the stored 1.0 / 0.0.
+template <int MODEL> __device__ __forceinline__ constexpr bool sens_is_const(int dd, int i)
+{
+    return (dd == 0 && i >= 2) || (MODEL == KIN && dd == 3 && i == 3);
+}
+__device__ __forceinline__ constexpr double sens_const(int dd, int i) { return dd == 0 && i == 2 ? 1.0 : 0.0; }
+
 // the transition sensitivities of a gradient request's stage (fields NX + 2 .. JS - 1 of its record).
 // Called BEFORE the cost part: the sixteen values leave for memory while the nearest-point search and
 // the cost are computed, and neither part holds the other's registers.
@@ -458,7 +469,7 @@ __device__ __forceinline__ void stage_sens_record(const DevCfg &c, const double 
 #pragma unroll
     for (int dd = 0; dd < NX; dd++) {
 #pragma unroll
-        for (int i = 0; i < NX; i++) put(NX + 2 + dd * NX + i, T[dd][i]);
+        for (int i = 0; i < NX; i++) if (!sens_is_const<MODEL>(dd, i)) put(NX + 2 + dd * NX + i, T[dd][i]);
     }
 }
 
@@ -486,14 +497,16 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
         for (int jj = 0; jj < 2; jj++) {
             double acc = get(k, NX + jj);
 #pragma unroll
-            for (int i = 0; i < NX; i++) acc = fma(get(k, NX + 2 + (NZ + jj) * NX + i), lam[i], acc);
+            for (int i = 0; i < NX; i++)
+                acc = fma(sens_is_const<MODEL>(NZ + jj, i) ? sens_const(NZ + jj, i) : get(k, NX + 2 + (NZ + jj) * NX + i), lam[i], acc);
             gu[jj] = acc;
         }
 #pragma unroll
         for (int jj = 0; jj < NZ; jj++) {
             double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; i++) acc = fma(get(k, NX + 2 + jj * NX + i), lam[i], acc);
+            for (int i = 0; i < NX; i++)
+                acc = fma(sens_is_const<MODEL>(jj, i) ? sens_const(jj, i) : get(k, NX + 2 + jj * NX + i), lam[i], acc);
             lz[jj] = acc;
         }
 #pragma unroll
