@@ -17,6 +17,10 @@ import os
 import sys
 import time
 
+# hardware queues for the solver's sub-batch streams (read by the HIP runtime at its initialisation;
+# the package sets the same default when it is imported first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -290,6 +294,7 @@ def main():
                        "batch_per_gpu": args.batch, "horizon": N, "nx": nx, "nu": 2, "m_c": m,
                        "lbfgs_memory": int(cfg.lbfgs_memory), "tolerance": cfg.alm_eps,
                        "max_total_inner": int(cfg.max_total_inner), "max_total_evals": int(cfg.max_total_evals),
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"agents sharded x{world}, no collective in the solve, final gather to rank 0"},
             "solver": {"converged_frac": conv, "inner_iters_mean": it_mean, "inner_iters_max": it_max,
                        "evals_per_solve_mean": ev_mean, "evals_per_solve_max": ev_max, "rounds": rounds,

@@ -8,6 +8,12 @@ import ctypes as C
 import os
 import subprocess
 
+# The HIP runtime maps a process's streams to GPU_MAX_HW_QUEUES hardware queues (4 unless set).  A
+# batched solve runs its sub-batch groups on streams of their own next to the caller's: with 8 queues
+# the solver takes four groups (+3.5 % solves/s at 65 536 agents).  Read by the runtime when
+# it initialises, i.e. at the first GPU call of the process: importing this package first is enough.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPC_LIB_PATH", os.path.join(_HERE, "libmpc_hip.so"))  # override: dev experiments
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("mpc_api.hip", "mpc_aux.hpp", "mpc_eval.hpp", "mpc_solver.hpp",

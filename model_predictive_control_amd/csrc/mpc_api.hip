@@ -76,6 +76,7 @@ struct mpc_handle {
     // sub-batch pipelining: the batch is split into groups that run their rounds on separate
     // streams, so that one group's (latency-bound) solver step overlaps another group's evaluation
     int ngroups = 0; // 0 = choose from the batch size
+    int hw_queues = 4; // hardware queues the HIP runtime maps this process's streams to (its GPU_MAX_HW_QUEUES, default 4)
     hipStream_t gstream[MPC_MAX_GROUPS] = {};
     hipEvent_t gevent[MPC_MAX_GROUPS + 1] = {};
     // staging buffers for the standalone entry points
@@ -222,6 +223,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->profile = p && p[0] == '1';
     const char *gq = getenv("MPC_GROUPS");
     h->ngroups = gq ? atoi(gq) : 0;
+    if (const char *hq = getenv("GPU_MAX_HW_QUEUES")) h->hw_queues = atoi(hq);
     *out = h;
     return MPC_OK;
 }
@@ -746,8 +748,12 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     Workspace gv[MPC_MAX_GROUPS];
     hipStream_t gs[MPC_MAX_GROUPS];
     // groups: contiguous agent ranges (multiples of 64), each with its own stream; measured at
-    // B = 65536: 1 group 0.258 s, 2 groups 0.224 s, 3 groups 0.220 s per solve
-    int G = h->ngroups > 0 ? h->ngroups : (B >= 24576 ? 3 : B >= 16384 ? 2 : 1);
+    // B = 65536 (round 1): 1 group 0.258 s, 2 groups 0.224 s, 3 groups 0.220 s per solve.  The HIP runtime
+    // maps a process's streams to GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says
+    // otherwise): with the caller's stream that leaves three for groups -- a fourth group shares a queue with
+    // another and its launches wait behind that one's (round 2: 3 groups 169.8 ms, 4 groups 259.8 ms with 4
+    // queues, 165.7 ms with 8; 5 groups 196 ms).  Four groups only when the queues are there.
+    int G = h->ngroups > 0 ? h->ngroups : (B >= 49152 && h->hw_queues >= 5 ? 4 : B >= 24576 ? 3 : B >= 16384 ? 2 : 1);
     if (G > MPC_MAX_GROUPS) G = MPC_MAX_GROUPS;
     while (G > 1 && B / G < 1024) G--;
     if (all_solo) G = 1;
