@@ -777,86 +777,111 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     }
     static const int check_env = getenv("MPC_CHECK_EVERY") ? atoi(getenv("MPC_CHECK_EVERY")) : 0;
     const int check_every = check_env > 0 ? check_env : 8;
-    long long round = 0;
-    bool active[MPC_MAX_GROUPS];
+    // Every group advances on its own: a window of `check_every` rounds is queued, its request counters are
+    // copied back behind it, and the host looks at them ONE WINDOW LATE -- a second window is already queued
+    // by then, so the stream does not run dry while the host decides.  The host serves whichever group's
+    // counters have arrived (event query, no blocking wait on one group while another's stream empties:
+    // the lock-step loop of round 1 left 60 - 200 us bubbles per window on the groups it was not waiting
+    // for, ~6 % of their streams' time in the r02d trace).
+    struct GroupRun { long long round = 0, window = 0; bool active = true; int slot_bound = 0; };
+    GroupRun gr[MPC_MAX_GROUPS];
     // upper bound on a group's requests per round: at most two per running agent (evaluation +
     // speculative gradient); every running agent has at least one request in a round and agents only
     // ever finish, so twice the requests seen at a poll bounds every later round
-    int slot_bound[MPC_MAX_GROUPS];
-    for (int g = 0; g < ng; g++) { active[g] = true; slot_bound[g] = 2 * gv[g].B; }
+    for (int g = 0; g < ng; g++) gr[g].slot_bound = 2 * gv[g].B;
     int nactive = ng;
     if (all_solo) {
         solo_events(0, gs[0], 0);
         launch_solo(h, gv[0], gs[0], w.solo_ctr, false, B, max_rounds);
         solo_events(0, gs[0], 1);
         solo_launches++;
-        active[0] = false; nactive = 0;
+        gr[0].active = false; nactive = 0;
     }
-    long long window = 0;
-    bool polled[2][MPC_MAX_GROUPS] = {{false}};
-    while (nactive > 0) {
-        const int cur = (int)(round & 1);
-        for (int g = 0; g < ng; g++) {
-            if (!active[g]) continue;
-            const Workspace &v = gv[g];
+    int rc_loop = MPC_OK;
+    auto queue_window = [&](int g) {            // `check_every` rounds of group g, then the copy of its counters
+        GroupRun &r = gr[g];
+        const Workspace &v = gv[g];
+        int cur = 0;
+        for (int i = 0; i < check_every && r.round < max_rounds; i++) {
+            cur = (int)(r.round & 1);
             int *lists = v.lists + (size_t)cur * 2 * v.Ls;
             int *counts = v.counts + cur * 4;
             int *counts_next = v.counts + (cur ^ 1) * 4;
             hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             // profile mode samples every 8th round: five events per sampled launch set
-            if (h->profile && (round & 7) == 0 && get_event(h, nev + 4)) { // all five exist, or none is used
+            if (h->profile && (r.round & 7) == 0 && get_event(h, nev + 4)) { // all five exist, or none is used
                 for (int k = 0; k < 5; k++) ev[k] = h->ev_pool[nev + k];
                 nev += 5;
             }
             if (ev[0]) (void)hipEventRecord(ev[0], gs[g]);
             launch_step(h, v, gs[g], lists, counts, counts_next);
             if (ev[1]) (void)hipEventRecord(ev[1], gs[g]);
-            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], slot_bound[g]);
+            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], r.slot_bound);
             if (ev[4]) (void)hipEventRecord(ev[4], gs[g]);
+            r.round++;
             rounds_done[g]++;
             launch_sets++;
             unfused_sets += !fused;
         }
-        round++;
-        if (round % check_every == 0 || round >= max_rounds) {
-            // Pipelined poll: the counters of this window are copied asynchronously and looked at one
-            // window later, so the streams never run dry while the host waits (a group that has
-            // finished runs one window of empty rounds more -- microseconds).
-            const int wb = (int)(window & 1);
-            for (int g = 0; g < ng; g++) {
-                polled[wb][g] = active[g];
-                if (!active[g]) continue;
-                if (!h->pollev[wb][g]) HIPCHK(hipEventCreateWithFlags(&h->pollev[wb][g], hipEventDisableTiming));
-                HIPCHK(hipMemcpyAsync(h->host_counts + 16 * wb + 2 * g, gv[g].counts + cur * 4, 2 * sizeof(int),
-                                      hipMemcpyDeviceToHost, gs[g]));
-                HIPCHK(hipEventRecord(h->pollev[wb][g], gs[g]));
-            }
-            const bool last = round >= max_rounds;
-            for (int pass = 0; pass < (last ? 2 : 1); pass++) {
-                // normally the previous window; at the round limit also the one just issued
-                const int pb = pass == 0 ? wb ^ 1 : wb;
-                if (pass == 0 && window == 0) continue;
-                for (int g = 0; g < ng; g++) {
-                    if (!polled[pb][g] || !active[g]) continue;
-                    HIPCHK(hipEventSynchronize(h->pollev[pb][g]));
-                    const int reqs = h->host_counts[16 * pb + 2 * g] + h->host_counts[16 * pb + 2 * g + 1];
-                    polled[pb][g] = false;
-                    if (reqs == 0) { active[g] = false; nactive--; continue; }
-                    slot_bound[g] = std::min(slot_bound[g], 2 * reqs);
-                    if (solo_ok && h->solo_max > 0 && reqs <= h->solo_max) {
-                        // few agents left in this group: they finish in the persistent kernel, each in
-                        // its own wave, instead of waiting for four launches per evaluation
-                        solo_events(g, gs[g], 0);
-                        launch_solo(h, gv[g], gs[g], w.solo_ctr + 2 * g, true, reqs, max_rounds);
-                        solo_events(g, gs[g], 1);
-                        solo_launches++;
-                        active[g] = false; nactive--;
-                    }
-                }
-            }
-            window++;
-            if (nactive > 0 && last) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
+        // (an event query that says "not ready" is recorded as the thread's last error too: not a failure)
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess && le != hipErrorNotReady) { rc_loop = MPC_E_HIP; return; }
+        const int wb = (int)(r.window & 1);
+        if (!h->pollev[wb][g] && hipEventCreateWithFlags(&h->pollev[wb][g], hipEventDisableTiming) != hipSuccess) { rc_loop = MPC_E_HIP; return; }
+        if (hipMemcpyAsync(h->host_counts + 16 * wb + 2 * g, v.counts + cur * 4, 2 * sizeof(int), hipMemcpyDeviceToHost, gs[g]) != hipSuccess ||
+            hipEventRecord(h->pollev[wb][g], gs[g]) != hipSuccess) { rc_loop = MPC_E_HIP; return; }
+        r.window++;
+    };
+    // what the counters of window `pb` say about group g; returns false when the group is done with rounds
+    auto decide = [&](int g, int pb) {
+        GroupRun &r = gr[g];
+        const int reqs = h->host_counts[16 * pb + 2 * g] + h->host_counts[16 * pb + 2 * g + 1];
+        if (reqs == 0) return false;
+        r.slot_bound = std::min(r.slot_bound, 2 * reqs);
+        if (solo_ok && h->solo_max > 0 && reqs <= h->solo_max) {
+            // few agents left in this group: they finish in the persistent kernel, each in
+            // its own wave, instead of waiting for four launches per evaluation
+            solo_events(g, gs[g], 0);
+            launch_solo(h, gv[g], gs[g], w.solo_ctr + 2 * g, true, reqs, max_rounds);
+            solo_events(g, gs[g], 1);
+            solo_launches++;
+            return false;
         }
+        return true;
+    };
+    // (tried: the groups started 40 / 80 / 160 us apart, so that one's step kernel meets another's K1 -- no change)
+    for (int g = 0; g < ng && nactive > 0; g++) queue_window(g);
+    for (int g = 0; g < ng && nactive > 0; g++) if (gr[g].round < max_rounds) queue_window(g);
+    while (nactive > 0 && rc_loop == MPC_OK) {
+        bool progressed = false;
+        for (int g = 0; g < ng; g++) {
+            GroupRun &r = gr[g];
+            if (!r.active) continue;
+            const long long oldest = r.window - (r.window >= 2 ? 2 : 1);    // the window whose counters are looked at next
+            const int pb = (int)(oldest & 1);
+            const hipError_t q = hipEventQuery(h->pollev[pb][g]);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) { rc_loop = MPC_E_HIP; break; }
+            progressed = true;
+            bool go = decide(g, pb);
+            if (go && r.round >= max_rounds) {
+                // the round limit: nothing more can be queued; the verdict is the LAST window's
+                if (r.window - oldest > 1) {
+                    if (hipEventSynchronize(h->pollev[pb ^ 1][g]) != hipSuccess) { rc_loop = MPC_E_HIP; break; }
+                    go = decide(g, pb ^ 1);
+                }
+                if (go) { rc_loop = MPC_E_LIMIT; break; }
+            }
+            if (!go) { r.active = false; nactive--; continue; }
+            queue_window(g);
+        }
+        if (!progressed) __builtin_ia32_pause();
+    }
+    if (rc_loop == MPC_E_LIMIT) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
+    if (rc_loop != MPC_OK) return fail(rc_loop, "mpc_solve_batch: HIP error in the round loop");
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess && le != hipErrorNotReady) return fail(MPC_E_HIP, std::string("mpc_solve_batch: ") + hipGetErrorString(le));
     }
     if (ng > 1) { // join
         for (int g = 0; g < ng; g++) {
