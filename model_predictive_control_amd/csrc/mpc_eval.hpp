@@ -170,11 +170,14 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
             kin_increment(c, u, half ? ph3 : ph1, kb, true, dxb, dyb);
             const double oxa = dpp_xchg<0xB1>(dxa), oya = dpp_xchg<0xB1>(dya);   // the partner's (quad_perm [1,0,3,2])
             const double oxb = dpp_xchg<0xB1>(dxb), oyb = dpp_xchg<0xB1>(dyb);
+            // the position is lane 0's to keep (it stores x and y, lane 1 heading and speed, which never see
+            // the position): its own increments are steps 0 and 1, its partner's steps 2 and 3 -- lane 1
+            // adds the same operands in an order that means nothing and never uses the result
             double px = x[0], py = x[1];
-            px = px + (half ? oxa : dxa); py = py + (half ? oya : dya);           // step 0
-            px = px + (half ? oxb : dxb); py = py + (half ? oyb : dyb);           // step 1
-            px = px + (half ? dxa : oxa); py = py + (half ? dya : oya);           // step 2
-            px = px + (half ? dxb : oxb); py = py + (half ? dyb : oyb);           // step 3
+            px = px + dxa; py = py + dya;                                         // step 0
+            px = px + dxb; py = py + dyb;                                         // step 1
+            px = px + oxa; py = py + oya;                                         // step 2
+            px = px + oxb; py = py + oyb;                                         // step 3
             x[0] = px; x[1] = py; x[2] = ph; x[3] = v;
         } else {
             stage_forward<KIN>(c, u, x);                 // some lane is out of range: the thread-per-request code
