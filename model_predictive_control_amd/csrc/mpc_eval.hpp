@@ -602,6 +602,10 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
     });
 }
 
+// (tried: four lanes per gradient request -- lane `role` of a DPP quad owning lambda[role] and one row of the
+// sensitivity block, lambda exchanged by quad broadcasts, the same fma chains, bit-identical, 6 loads per
+// lane and stage instead of 19 and four times the waves -- 37.8 -> 47.9 us per launch: K1c is bound by the
+// record bytes coming back (104 MB per launch, written by K1b a moment before), not by its dependent trips)
 template <int MODEL>
 __global__ void __launch_bounds__(64)
 adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm)
