@@ -12,7 +12,19 @@ import subprocess
 # batched solve runs its sub-batch groups on streams of their own next to the caller's: with 8 queues
 # the solver takes four groups (+3.5 % solves/s at 65 536 agents).  Read by the runtime when
 # it initialises, i.e. at the first GPU call of the process: importing this package first is enough.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+def _default_hw_queues():
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    try:    # too late once the runtime is up (it has read its environment): the solver then keeps to three groups
+        import torch
+        if torch.cuda.is_initialized():
+            return
+    except Exception:
+        pass
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
+_default_hw_queues()
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPC_LIB_PATH", os.path.join(_HERE, "libmpc_hip.so"))  # override: dev experiments
