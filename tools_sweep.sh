@@ -1,8 +1,9 @@
 #!/bin/bash
 # Development: bench.py under a list of environment settings:  bash tools_sweep.sh "MPC_GROUPS=2" "MPC_SOLO_MAX=512 MPC_GROUPS=3" ...
+# (SWEEP_ARGS="--model 1 --horizon 12" in the environment adds bench.py arguments)
 mkdir -p gpurun_out/sweep
 for cfg in "$@"; do
-  env $cfg python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-pass > gpurun_out/sweep/b.json 2>/dev/null
+  env $cfg python bench.py --steps ${SWEEP_STEPS:-8} --warmup 2 --no-cpu-baseline --no-kernel-pass $SWEEP_ARGS > gpurun_out/sweep/b.json 2>/dev/null
   python - "$cfg" <<PY
 import json, sys
 d = json.load(open("gpurun_out/sweep/b.json"))
