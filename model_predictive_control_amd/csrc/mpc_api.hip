@@ -15,6 +15,7 @@
 using namespace mpc;
 
 #define MPC_MAX_GROUPS 8
+#define MPC_GRID_MAX_ROWS 1024   // centerline rows the nearest-point grid is built for (256 KB each)
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -51,6 +52,7 @@ struct mpc_handle {
     double *cl_gmeta = nullptr, *cl_gxy = nullptr;   // grid placement [C][GRID_META], interleaved points [C][S][2]
     unsigned *cl_gcells = nullptr;                   // [C][GRID_CELLS]
     int cl_grid_cap = 0;                             // rows the grid buffers hold
+    bool cl_grid_ok = false;                         // the grid describes the prepared table (not built for > MPC_GRID_MAX_ROWS rows)
     int solo_all = 4096;        // a batch of at most this many agents runs in the persistent kernel from the start
                                 // (MPC_SOLO_ALL; measured: kinematic 4 096 agents 62.8 -> 53.3 ms, 8 192 worse; Pacejka 1 024)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
@@ -389,7 +391,7 @@ static NearTab near_for(const mpc_handle *h, const double *cl)
     NearTab nt = {nullptr, nullptr, nullptr, nullptr};
     if (!h->cl_boxes_for || h->cl_boxes_for != cl) return nt;
     if (h->nearest_mode == 1 && h->cl_boxes) nt.boxes = h->cl_boxes;
-    if (h->nearest_mode == 2 && h->cl_gmeta) { nt.gmeta = h->cl_gmeta; nt.gcells = h->cl_gcells; nt.gxy = h->cl_gxy; }
+    if (h->nearest_mode == 2 && h->cl_gmeta && h->cl_grid_ok) { nt.gmeta = h->cl_gmeta; nt.gcells = h->cl_gcells; nt.gxy = h->cl_gxy; }
     return nt;
 }
 
@@ -408,7 +410,10 @@ extern "C" int mpc_centerline_blocks(mpc_handle *h, const double *cl, int C, voi
         h->cl_boxes_bytes = bytes;
     }
     if (!blocks && h->cl_boxes) { HIPCHK(hipFree(h->cl_boxes)); h->cl_boxes = nullptr; h->cl_boxes_bytes = 0; }
-    if (C > h->cl_grid_cap) {
+    // the grid costs 256 KB per centerline row: a table with one row per agent keeps the full scan
+    const bool grid = C <= MPC_GRID_MAX_ROWS;
+    h->cl_grid_ok = false;
+    if (grid && C > h->cl_grid_cap) {
         if (h->cl_gmeta) { HIPCHK(hipFree(h->cl_gmeta)); h->cl_gmeta = nullptr; }
         if (h->cl_gxy) { HIPCHK(hipFree(h->cl_gxy)); h->cl_gxy = nullptr; }
         if (h->cl_gcells) { HIPCHK(hipFree(h->cl_gcells)); h->cl_gcells = nullptr; }
@@ -421,9 +426,12 @@ extern "C" int mpc_centerline_blocks(mpc_handle *h, const double *cl, int C, voi
     }
     hipStream_t s = (hipStream_t)stream;
     if (blocks) hipLaunchKernelGGL(cl_blocks_kernel, grid_for(C * NB, 256), dim3(256), 0, s, c, cl, C, h->cl_boxes);
-    hipLaunchKernelGGL(cl_grid_meta_kernel, dim3((unsigned)C), dim3(64), 0, s, c, cl, C, h->cl_gmeta, h->cl_gxy);
-    hipLaunchKernelGGL(cl_grid_cells_kernel, dim3(GRID_CELLS / 256, C), dim3(256), 0, s, c, cl, C, h->cl_gmeta, h->cl_gcells);
+    if (grid) {
+        hipLaunchKernelGGL(cl_grid_meta_kernel, dim3((unsigned)C), dim3(64), 0, s, c, cl, C, h->cl_gmeta, h->cl_gxy);
+        hipLaunchKernelGGL(cl_grid_cells_kernel, dim3(GRID_CELLS / 256, C), dim3(256), 0, s, c, cl, C, h->cl_gmeta, h->cl_gcells);
+    }
     HIPCHK(hipGetLastError());
+    h->cl_grid_ok = grid;
     h->cl_boxes_for = cl; h->cl_boxes_rows = C;
     return MPC_OK;
 }

@@ -175,6 +175,27 @@ def test_block_pruned_nearest_point_is_exact(dev, O, S, mode):
     assert torch.equal(p1, p2) and torch.equal(g1, g2)
 
 
+def test_nearest_grid_keeps_to_small_tables(dev, O):
+    """A centerline table with one row per agent (more rows than the grid is built for, 256 KB each) takes
+    the full scan: same indices as with the search switched off, and as the oracle's."""
+    S, C = 100, 1100
+    cfg, ocfg = both(O, 0, 8, S=S)
+    eng = mp.BatchedMPC(cfg, dev)
+    rng = np.random.default_rng(5)
+    base = np.array([[i / 10 - 0.1, 0] for i in range(S)])
+    tab = np.stack([(base + [0.0, 0.01 * r]).ravel(order="F") for r in range(C)])
+    pose = np.stack([rng.uniform(0, 9, C), rng.uniform(-1, 12, C), np.zeros(C)], 1)
+    ci = np.arange(C, dtype=np.int32)
+    P, TAB, CI = T(pose, dev), T(tab, dev), T(ci, dev, torch.int32)
+    eng.set_nearest_blocks(2)
+    e2, i2 = eng.stage_errors(P, TAB, CI)
+    eng.set_nearest_blocks(0)
+    e0, i0 = eng.stage_errors(P, TAB, CI)
+    assert torch.equal(i2, i0) and torch.equal(e2, e0)
+    oidx = np.array([O.nearest(ocfg, pose[b, :2], tab[b]) for b in range(0, C, 37)])
+    assert np.array_equal(i2.cpu().numpy()[::37], oidx)
+
+
 @pytest.mark.parametrize("wrap", [0, 1, 2])
 def test_wrap_modes_match_oracle(dev, O, wrap):
     cfg, ocfg = both(O, 1, 12, wrap_mode=wrap)
