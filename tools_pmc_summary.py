@@ -50,7 +50,7 @@ for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 summary = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
               "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-pass (one batched solve of 65536 agents, "
-              "3 sub-batch groups), profile %s" % tag,
+              "the default sub-batch groups: 4 with GPU_MAX_HW_QUEUES >= 5, else 3), profile %s" % tag,
     "correction": "gfx950: FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md HBM "
                   "section): read side doubled; other access widths uncalibrated",
 }
