@@ -147,6 +147,15 @@ int mpc_solve_batch(mpc_handle *h, int B, const double *x0, const double *cl,
                     const int32_t *cl_index, double *U, double *lambda, double *stats,
                     void *stream);
 
+/* The same solve without holding the caller's thread: the round loop (launches and counter polls, host
+ * code) runs on a worker thread of the handle; mpc_solve_wait blocks until the solve is complete (all
+ * results in the caller's buffers, the stream drained) and returns its code.  One solve in flight per
+ * handle; no other call on the handle between the two.  ("async on the given stream".) */
+int mpc_solve_batch_async(mpc_handle *h, int B, const double *x0, const double *cl,
+                          const int32_t *cl_index, double *U, double *lambda, double *stats,
+                          void *stream);
+int mpc_solve_wait(mpc_handle *h);
+
 /* f-1 (main.py:121-146): T closed-loop steps on device: solve, apply u0, plant step f_d.
  * x [B][nx] inout; U, lambda warm start inout; traj_x [B][T][nx], traj_u [B][T][2] (NULL ok);
  * shift != 0 shifts the warm start by one stage (the reference does not: controller.py:57).

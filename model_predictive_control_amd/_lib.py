@@ -41,7 +41,7 @@ ST_CONVERGED = 1
 EXPORTS = [
     "mpc_default_config", "mpc_nx", "mpc_m", "mpc_create", "mpc_destroy", "mpc_last_error",
     "mpc_rhs", "mpc_rollout", "mpc_stage_errors", "mpc_stage_cost", "mpc_eval_cost_grad", "mpc_prox_step",
-    "mpc_lbfgs_apply", "mpc_solve_batch", "mpc_closed_loop", "mpc_last_solve_info",
+    "mpc_lbfgs_apply", "mpc_solve_batch", "mpc_solve_batch_async", "mpc_solve_wait", "mpc_closed_loop", "mpc_last_solve_info",
     "mpc_last_solve_info2", "mpc_math_probe", "mpc_set_groups", "mpc_last_kernel_ms", "mpc_lane_payoff",
     "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
     "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks",
@@ -115,6 +115,8 @@ def load():
     L.mpc_prox_step.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_lbfgs_apply.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_solve_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_solve_batch_async.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_solve_wait.argtypes = [vp]
     L.mpc_closed_loop.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_last_solve_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double),

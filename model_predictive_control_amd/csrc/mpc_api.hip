@@ -9,7 +9,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mpc;
@@ -77,6 +80,15 @@ struct mpc_handle {
     std::vector<hipEvent_t> ev_pool;
     // sub-batch pipelining: the batch is split into groups that run their rounds on separate
     // streams, so that one group's (latency-bound) solver step overlaps another group's evaluation
+    // mpc_solve_batch_async: the host side of a solve (its round loop) on a worker thread of the handle
+    struct AsyncJob { int B; const double *x0, *cl; const int32_t *cl_index; double *U, *lambda, *stats; void *stream; };
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    AsyncJob job{};
+    bool job_posted = false, job_running = false, job_done = false, worker_quit = false;
+    int job_rc = MPC_OK;
+    std::string job_err;
     int ngroups = 0; // 0 = choose from the batch size
     int hw_queues = 4; // hardware queues the HIP runtime maps this process's streams to (its GPU_MAX_HW_QUEUES, default 4)
     hipStream_t gstream[MPC_MAX_GROUPS] = {};
@@ -233,6 +245,11 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
 extern "C" int mpc_destroy(mpc_handle *h)
 {
     if (!h) return MPC_OK;
+    if (h->worker.joinable()) {           // a solve still running finishes first
+        { std::lock_guard<std::mutex> lk(h->mu); h->worker_quit = true; }
+        h->cv.notify_all();
+        h->worker.join();
+    }
     (void)hipSetDevice(h->device);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
@@ -960,6 +977,55 @@ extern "C" int mpc_solve_batch(mpc_handle *h, int B, const double *x0, const dou
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     return MPC_OK;
+}
+
+// The round loop of a solve is host code (launches, counter polls): the asynchronous form runs it on a
+// worker thread owned by the handle, so the caller gets its thread back at once and may run a second
+// handle's solve, or its own work, beside it.  One solve in flight per handle.
+static void async_worker(mpc_handle *h)
+{
+    for (;;) {
+        mpc_handle::AsyncJob j;
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv.wait(lk, [&] { return h->job_posted || h->worker_quit; });
+            if (!h->job_posted) return;   // quit
+            j = h->job; h->job_posted = false; h->job_running = true;
+        }
+        const int rc = mpc_solve_batch(h, j.B, j.x0, j.cl, j.cl_index, j.U, j.lambda, j.stats, j.stream);
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->job_rc = rc; h->job_err = rc ? g_err : std::string();
+            h->job_running = false; h->job_done = true;
+        }
+        h->cv.notify_all();
+    }
+}
+
+extern "C" int mpc_solve_batch_async(mpc_handle *h, int B, const double *x0, const double *cl,
+                                     const int32_t *cl_index, double *U, double *lambda, double *stats,
+                                     void *stream)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_solve_batch_async: null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->job_posted || h->job_running || h->job_done)
+        return fail(MPC_E_ARG, "mpc_solve_batch_async: a solve of this handle is in flight (mpc_solve_wait first)");
+    if (!h->worker.joinable()) h->worker = std::thread(async_worker, h);
+    h->job = {B, x0, cl, cl_index, U, lambda, stats, stream};
+    h->job_posted = true;
+    h->cv.notify_all();
+    return MPC_OK;
+}
+
+extern "C" int mpc_solve_wait(mpc_handle *h)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_solve_wait: null handle");
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (!h->job_posted && !h->job_running && !h->job_done) return fail(MPC_E_ARG, "mpc_solve_wait: no solve in flight");
+    h->cv.wait(lk, [&] { return h->job_done; });
+    h->job_done = false;
+    if (h->job_rc != MPC_OK) g_err = h->job_err;
+    return h->job_rc;
 }
 
 extern "C" int mpc_closed_loop(mpc_handle *h, int B, int T, int shift, double *x, const double *cl,

@@ -193,6 +193,29 @@ class BatchedMPC:
                                             _ptr(lam), _ptr(stats), self._stream()))
         return U, lam, stats
 
+    def solve_async(self, x0, centerline, U, lam=None, cl_index=None):
+        """The same solve without holding the caller's thread (mpc_solve_batch_async): returns a function;
+        calling it waits for the solve (mpc_solve_wait) and returns (U*, lambda*, stats).  One solve in
+        flight per engine; no other call on the engine in between."""
+        B = x0.shape[0]
+        self._chk(x0, (B, self.nx), "x0"); self._chk(U, (B, self.n), "U")
+        cl = self._centerline(centerline, cl_index, B)
+        U = U.clone()
+        if self.m:
+            lam = torch.zeros(B, self.m, dtype=torch.float64, device=self.device) if lam is None else lam.clone()
+            self._chk(lam, (B, self.m), "lam")
+        else:
+            lam = None
+        stats = self._empty(B, _lib.NSTATS)
+        keep = (x0, cl, cl_index, U, lam, stats)      # the buffers stay alive until the wait
+        _lib.check(self.lib.mpc_solve_batch_async(self._h, B, _ptr(x0), _ptr(cl), _ptr(cl_index), _ptr(U),
+                                                  _ptr(lam), _ptr(stats), self._stream()))
+
+        def wait():
+            _lib.check(self.lib.mpc_solve_wait(self._h))
+            return keep[3], keep[4], keep[5]
+        return wait
+
     def closed_loop(self, x, centerline, U, T, lam=None, cl_index=None, shift=False):
         """f-1 (main.py:121-146) for B agents: returns (x_T, U, lam, traj_x[B,T,nx], traj_u[B,T,2],
         failures[B], stats of the last solve)."""

@@ -175,6 +175,36 @@ def test_block_pruned_nearest_point_is_exact(dev, O, S, mode):
     assert torch.equal(p1, p2) and torch.equal(g1, g2)
 
 
+def test_async_solve_is_the_same_solve(dev):
+    """mpc_solve_batch_async / mpc_solve_wait (async on the given stream): the round loop on the
+    handle's worker thread gives the same bits as the blocking call; two handles solve side by side; a second
+    solve on a busy handle and a wait without a solve are refused."""
+    N, B = 12, 3000
+    cl = T(straight_centerline(), dev)
+    X0 = T(synthetic_states(0, B, seed=3), dev)
+    U0 = T(np.tile([1.0, 0.0], (B, N)), dev)
+    e1 = mp.BatchedMPC(mp.default_config(0, N), dev)
+    e2 = mp.BatchedMPC(mp.default_config(0, N), dev)
+    Us, _, ss = e1.solve(X0, cl, U0)
+    w1 = e1.solve_async(X0, cl, U0)
+    w2 = e2.solve_async(X0[:1500], cl, U0[:1500])
+    with pytest.raises(RuntimeError):
+        e1.solve_async(X0, cl, U0)
+    Ua, _, sa = w1()
+    Ub, _, sb = w2()
+    assert torch.equal(Ua, Us) and torch.equal(sa, ss)
+    assert torch.equal(Ub, Us[:1500]) and torch.equal(sb[:, 0], ss[:1500, 0])
+    with pytest.raises(RuntimeError):
+        _lib_check_wait(e1)
+    Uc, _, _ = e1.solve(X0, cl, U0)                      # the handle is free again
+    assert torch.equal(Uc, Us)
+
+
+def _lib_check_wait(eng):
+    from model_predictive_control_amd import _lib
+    _lib.check(eng.lib.mpc_solve_wait(eng._h))
+
+
 def test_nearest_grid_keeps_to_small_tables(dev, O):
     """A centerline table with one row per agent (more rows than the grid is built for, 256 KB each) takes
     the full scan: same indices as with the search switched off, and as the oracle's."""
