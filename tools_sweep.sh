@@ -3,7 +3,7 @@
 # (SWEEP_ARGS="--model 1 --horizon 12" in the environment adds bench.py arguments)
 mkdir -p gpurun_out/sweep
 for cfg in "$@"; do
-  env $cfg python bench.py --steps ${SWEEP_STEPS:-8} --warmup 2 --no-cpu-baseline --no-kernel-pass $SWEEP_ARGS > gpurun_out/sweep/b.json 2>/dev/null
+  env $cfg python bench.py --steps ${SWEEP_STEPS:-8} --warmup 2 --no-cpu-baseline --no-kernel-pass --no-pipeline-pass $SWEEP_ARGS > gpurun_out/sweep/b.json 2>/dev/null
   python - "$cfg" <<PY
 import json, sys
 d = json.load(open("gpurun_out/sweep/b.json"))
