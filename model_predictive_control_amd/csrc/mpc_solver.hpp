@@ -21,7 +21,10 @@ enum {
     R_OUT_EPS, R_OUT_DELTA, R_PSI_OUT, R_PSIE,
     R_PHASE, R_K, R_LIDX, R_LFULL, R_NOPROG, R_NJ, R_OUTER, R_FIRST, R_INITRED, R_PENRED,
     R_INNER_TOT, R_INNER_FAIL, R_STATUS, R_NEVALS, R_MAXIT, R_OVERWRITE, R_FALLBACK, R_PS_STATUS,
-    R_PS_ITERS, R_OUT_OF_ITER, R_NGRAD, R_LBROWS, R_SPEC, R_SPEC_GAMMA, R_NSPEC, R_NSPEC_USED, R_NCOST, R_USED
+    R_PS_ITERS, R_OUT_OF_ITER, R_NGRAD, R_LBROWS, R_SPEC, R_SPEC_GAMMA, R_NSPEC, R_NSPEC_USED, R_NCOST,
+    // the inner solve in progress (smallest stop measure seen, evaluation count at its start) and the memo of
+    // the last one that failed and was backtracked over without constraints (see PH_OUTER_BEGIN)
+    R_RUN_MINEPS, R_RUN_EV0, R_MEMO_STATUS, R_MEMO_ITERS, R_MEMO_EVALS, R_MEMO_MINEPS, R_MEMO_EPS, R_USED
 };
 static_assert(R_USED <= REC, "record too small");
 
@@ -521,6 +524,13 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     RecI out_of_iter{rv, lane, R_OUT_OF_ITER};
     RecI spec{rv, lane, R_SPEC};
     RecD spec_gamma{rv, lane, R_SPEC_GAMMA};
+    RecD run_mineps{rv, lane, R_RUN_MINEPS};
+    RecI run_ev0{rv, lane, R_RUN_EV0};
+    RecI memo_status{rv, lane, R_MEMO_STATUS};
+    RecI memo_iters{rv, lane, R_MEMO_ITERS};
+    RecI memo_evals{rv, lane, R_MEMO_EVALS};
+    RecD memo_mineps{rv, lane, R_MEMO_MINEPS};
+    RecD memo_eps{rv, lane, R_MEMO_EPS};
     double t_pp, t_gp;
     int lb_rows = 0, n_grad = 0;
     int req = REQ_NONE;
@@ -574,6 +584,24 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             const int budget = c.max_total_inner - inner_tot;
             max_it = c.max_iter < budget ? c.max_iter : budget;
             overwrite = out_of_iter || out_of_pen || (max_it >= budget);
+            // A failed inner solve that the outer loop backtracks over WITHOUT constraints (m = 0) leaves x
+            // where it was and changes only the tolerance: the retry is the same deterministic computation
+            // -- same start, same L-BFGS reset, same evaluations -- and ends the same way unless the new
+            // tolerance lets the stop test fire earlier (it cannot while it is below every stop measure the
+            // failed run saw), the iteration limit moved inside the run, or this retry is the one whose
+            // result is kept (overwrite).  alpaqa walks through up to 20 such retries, ~120 evaluations
+            // each, and a batch waits for the one agent that does (the Pacejka benchmark's slowest: 2 400 of
+            // its 3 081 evaluations).  The memo replays the outcome and the counts, not the evaluations: the
+            // result and every statistic are those of the run that was not repeated.
+            if (memo_status != 0 && m == 0 && !overwrite && c.max_total_evals == 0 &&
+                memo_iters < max_it && eps < memo_mineps) {
+                ps_status = memo_status; ps_iters = memo_iters; ps_eps = memo_eps;
+                nevals += memo_evals;
+                phase = PH_INNER_EXIT;
+                break;
+            }
+            memo_status = 0;
+            run_mineps = INFINITY; run_ev0 = nevals;
             // inner solver start: xk <- x, L-BFGS reset, Lipschitz estimate by finite differences
             lidx = 0; lfull = 0; noprog = 0; k = 0; spec = 0;
             const Row<NE> x = ldrow<NE>(w.xo + an, n, lane);
@@ -675,6 +703,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
         // ------------------------------------------- stop test + structured direction (K3 setup)
         case PH_AFTER_DL: {
             const double epsk = sqrt(pp) / gamma; // ProjGradNorm2, controller.py:29
+            if (epsk < run_mineps) run_mineps = epsk;
             const int stop = epsk <= eps ? ST_CONVERGED
                            : (c.max_total_evals > 0 && nevals >= c.max_total_evals) ? ST_MAXTIME
                            : k == max_it ? ST_MAXITER
@@ -891,6 +920,15 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             const int out_of_time = inner_tot >= c.max_total_inner ||
                                     (c.max_total_evals > 0 && nevals >= c.max_total_evals);
             const int backtrack = !conv && !overwrite && !out_of_time;
+            // (memo for PH_OUTER_BEGIN: only a run that ended without progress / non-finite inside its limits)
+            if (backtrack && m == 0 && (ps_status == ST_NOPROGRESS || ps_status == ST_NOTFINITE)) {
+                if (memo_status == 0) {       // a real run: remember it (a replayed one keeps the memo as it is)
+                    memo_status = ps_status; memo_iters = ps_iters; memo_evals = nevals - run_ev0;
+                    memo_mineps = run_mineps; memo_eps = ps_eps;
+                }
+            } else {
+                memo_status = 0;
+            }
             if (backtrack) {
                 if (!first) {
                     Delta = fmax(1.0, Delta * c.Delta_lower);

@@ -175,6 +175,42 @@ def test_block_pruned_nearest_point_is_exact(dev, O, S, mode):
     assert torch.equal(p1, p2) and torch.equal(g1, g2)
 
 
+def test_failed_retries_are_replayed_not_recomputed(dev, O):
+    """An agent whose inner solve stalls (NoProgress) without constraints is retried by the outer loop from
+    the same point up to 20 times (a-8); the retries are the same deterministic computation, and the solver
+    replays their outcome and counts instead of evaluating them again.  The Pacejka benchmark's slowest
+    agent (2 400 of its ~3 000 evaluations are such retries): same status as the oracle and its outer iterations within 2,
+    which does walk through them, evaluation and iteration counts within its own run-to-run spread, the
+    same bits whether it is solved alone (persistent kernel) or inside a batch (rounds), and far fewer
+    evaluations EXECUTED than COUNTED."""
+    N = 12
+    import bench
+    x_stall = bench.synthetic_states(1, 48296, 48297)
+    cfg, ocfg = both(O, 1, N)
+    cl_np = straight_centerline()
+    cl = T(cl_np, dev)
+    U0 = np.tile([1.0, 0.0], (1, N))
+    Uo, _, so = O.solve_batch(ocfg, x_stall, cl_np, U0, nthreads=1)
+    assert so[0, 0] == 1 and so[0, 1] >= 30                     # the oracle: converged after the retries
+    eng = mp.BatchedMPC(cfg, dev)
+    U1, _, s1 = eng.solve(T(x_stall, dev), cl, T(U0, dev))
+    info = eng.last_solve_info()
+    s1 = s1.cpu().numpy()
+    # same status; the 20 retries are there on both sides (after them the two runs part in the last bits of a
+    # flat problem: one outer iteration more or less to reach 1e-6)
+    assert s1[0, 0] == 1 and abs(s1[0, 1] - so[0, 1]) <= 2
+    assert abs(s1[0, 7] - so[0, 7]) <= 0.1 * so[0, 7] and abs(s1[0, 2] - so[0, 2]) <= 0.1 * so[0, 2]
+    executed = info["evals_grad"] + info["evals_cost"]
+    assert executed < 0.5 * s1[0, 7], (executed, s1[0, 7])      # counted as the reference counts, not executed
+    rel = np.abs(U1.cpu().numpy() - Uo).max() / np.abs(Uo).max()
+    assert rel < 2e-4
+    # inside a batch that takes the round path (and ends in the persistent kernel): the same bits
+    B = 1500
+    X = synthetic_states(1, B, seed=11); X[777] = x_stall[0]
+    Ub, _, sb = eng.solve(T(X, dev), cl, T(np.tile([1.0, 0.0], (B, N)), dev))
+    assert torch.equal(Ub[777], U1[0]) and np.array_equal(sb.cpu().numpy()[777], s1[0])
+
+
 def test_async_solve_is_the_same_solve(dev):
     """mpc_solve_batch_async / mpc_solve_wait (async on the given stream): the round loop on the
     handle's worker thread gives the same bits as the blocking call; two handles solve side by side; a second
