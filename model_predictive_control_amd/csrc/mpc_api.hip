@@ -376,6 +376,9 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         if (evb) (void)hipEventRecord(evb, s);
         return true;
     }
+    // (tried: nblk rounded up to a multiple of 8, which puts every stage block of slot block sb and its adjoint
+    // block on XCD sb % 8 so that K1c could read records from the L2 they were written to -- no change: the 13 MB
+    // of records per XCD and launch pass through a 4 MB L2 long before K1c starts)
     const size_t xy_lds = (shared && w.near.gmeta) ? sizeof(double) * 2 * (size_t)c.S : 0;
     if (shared)
         hipLaunchKernelGGL((stage_kernel<MODEL, true>), dim3((unsigned)(nblk * c.N)), dim3(64), xy_lds, s, c, w, counts, nG, nC, nblk);
