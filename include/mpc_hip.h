@@ -18,7 +18,9 @@
  *  - centerlines: table cl [C][2S], each row flat [x_0..x_{S-1}, y_0..y_{S-1}]
  *    (main.py:113 ravel(order='F')); cl_index [B] int32 selects a row per agent, NULL = row 0.
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*) except
- *    mpc_solve_batch, which polls a device counter and returns when the batch is solved.
+ *    mpc_solve_batch / mpc_closed_loop, which poll device counters and return when the batch is solved.
+ *  - between mpc_solve_batch_async and mpc_solve_wait the handle belongs to its worker thread: every
+ *    other call on it returns MPC_E_ARG without touching it.
  *  - return value: 0 on success, negative MPC_E_* otherwise; mpc_last_error() explains.
  *    No exceptions cross the ABI.  One handle per GPU/stream; a handle is not thread-safe.
  */
@@ -156,7 +158,10 @@ int mpc_solve_batch_async(mpc_handle *h, int B, const double *x0, const double *
                           void *stream);
 int mpc_solve_wait(mpc_handle *h);
 
-/* f-1 (main.py:121-146): T closed-loop steps on device: solve, apply u0, plant step f_d.
+/* f-1 (main.py:121-146): T closed-loop steps with states, controls and warm starts resident on the
+ * device: per step one mpc_solve_batch (whose round loop is HOST code: launches and counter polls, like
+ * any solve) followed by one kernel that applies u0 and advances the plant with f_d.  Data never leaves
+ * the device; control returns to the host once per round window, as in every solve.
  * x [B][nx] inout; U, lambda warm start inout; traj_x [B][T][nx], traj_u [B][T][2] (NULL ok);
  * shift != 0 shifts the warm start by one stage (the reference does not: controller.py:57).
  * fail_count[B] int32 accumulates status != Converged (controller.py:64), NULL ok. */
@@ -199,8 +204,26 @@ int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int6
  * MPC_SOLO_MAX (both) and MPC_SOLO_ALL (the batch bound alone).  Results do not depend on it. */
 int mpc_set_solo_max(mpc_handle *h, int max_requests);
 /* sub-batch pipelining: the batch is split into `groups` contiguous ranges whose rounds run on
- * separate HIP streams (0 = automatic: 3 from 24576 agents, 2 from 16384, else 1; at most 8) */
+ * separate HIP streams (0 = automatic: 4 from 49152 agents when the runtime runs five streams side by
+ * side -- measured at mpc_create, see mpc_stream_concurrency --, 3 from 24576, 2 from 16384, else 1; at
+ * most 8; never fewer than 1024 agents per group).  Results do not depend on it. */
 int mpc_set_groups(mpc_handle *h, int groups);
+/* streams = how many of this process's streams the HIP runtime runs side by side, as far as the solver
+ * cares: 5 (five or more) or 4 (fewer).  Measured when the handle is created (an idling kernel on the null
+ * stream and on four streams of the handle), NOT read from GPU_MAX_HW_QUEUES: the runtime reads that
+ * variable once, when it initialises, and 4 is its default -- a C caller that wants four groups exports
+ * GPU_MAX_HW_QUEUES >= 5 before its first HIP call (the Python package does so at import).
+ * groups_last = sub-batch groups of the last solve.  Either pointer may be NULL. */
+int mpc_stream_concurrency(mpc_handle *h, int *streams, int *groups_last);
+/* on != 0 (default): a failed inner solve that the outer loop backtracks over without constraints is
+ * replayed from a memo -- same outcome, same counted statistics, no evaluations executed -- instead of
+ * being recomputed; 0 (or the environment MPC_NO_MEMO at mpc_create): recomputed, as the reference walks.
+ * Controls, multipliers and all MPC_NSTATS statistics are bit-identical either way. */
+int mpc_set_memo(mpc_handle *h, int on);
+/* test aid: at most `rounds` rounds (persistent kernel: evaluations per agent) per solve; a solve that
+ * needs more returns MPC_E_LIMIT with the agents it could not finish left as they are (0 = the built-in
+ * guard alone, which no valid solve reaches) */
+int mpc_set_round_limit(mpc_handle *h, int64_t rounds);
 /* on != 0: bracket every kernel of mpc_solve_batch with HIP events on the solve's stream so that
  * mpc_last_solve_info reports eval_ms / step_ms (also enabled by the environment MPC_PROFILE=1) */
 int mpc_set_profile(mpc_handle *h, int on);

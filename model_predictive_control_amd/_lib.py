@@ -45,7 +45,8 @@ EXPORTS = [
     "mpc_lbfgs_apply", "mpc_solve_batch", "mpc_solve_batch_async", "mpc_solve_wait", "mpc_closed_loop", "mpc_last_solve_info",
     "mpc_last_solve_info2", "mpc_math_probe", "mpc_set_groups", "mpc_last_kernel_ms", "mpc_lane_payoff",
     "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
-    "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks",
+    "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks", "mpc_set_memo",
+    "mpc_set_round_limit", "mpc_stream_concurrency",
 ]
 
 
@@ -133,6 +134,9 @@ def load():
     L.mpc_set_solo_max.argtypes = [vp, ci]
     L.mpc_centerline_blocks.argtypes = [vp, vp, ci, vp]
     L.mpc_set_nearest_blocks.argtypes = [vp, ci]
+    L.mpc_set_memo.argtypes = [vp, ci]
+    L.mpc_set_round_limit.argtypes = [vp, C.c_int64]
+    L.mpc_stream_concurrency.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for name in EXPORTS:
         if name != "mpc_last_error":
             getattr(L, name).restype = ci

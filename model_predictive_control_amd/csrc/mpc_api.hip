@@ -6,6 +6,7 @@
 #include "mpc_game.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -90,7 +91,9 @@ struct mpc_handle {
     int job_rc = MPC_OK;
     std::string job_err;
     int ngroups = 0; // 0 = choose from the batch size
-    int hw_queues = 4; // hardware queues the HIP runtime maps this process's streams to (its GPU_MAX_HW_QUEUES, default 4)
+    int groups_last = 0; // sub-batch groups of the last solve
+    long long round_limit = 0; // mpc_set_round_limit: cap on the rounds / persistent-kernel trips of a solve (0 = the guard alone)
+    int hw_queues = 4; // streams of this process the HIP runtime runs side by side: 5 (or more) / 4 (or fewer), measured at mpc_create
     hipStream_t gstream[MPC_MAX_GROUPS] = {};
     hipEvent_t gevent[MPC_MAX_GROUPS + 1] = {};
     // staging buffers for the standalone entry points
@@ -180,6 +183,7 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.max_total_num_retries = c.max_total_num_retries; d.max_total_inner = c.max_total_inner;
     d.max_total_evals = c.max_total_evals;
     d.no_spec = getenv("MPC_NO_SPEC") != nullptr;
+    d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
     d.h = c.Ts / c.nfe; d.v_ref = c.v_ref;
     for (int i = 0; i < 6; i++) { d.w[i] = c.cost_w[i]; d.g_off[i] = c.g_off[i]; d.D_lb[i] = c.D_lb[i]; d.D_ub[i] = c.D_ub[i]; }
     d.lf = c.veh[1]; d.lr = c.veh[2]; d.mass = c.veh[7]; d.inv_mass = 1.0 / c.veh[7]; d.inv_iz = 1.0 / c.veh[8];
@@ -196,6 +200,44 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.lip_eps = c.lip_eps; d.lip_delta = c.lip_delta; d.Lgamma = c.Lgamma_factor; d.L_min = c.L_min;
     d.L_max = c.L_max; d.tau_min = c.tau_min; d.qub_tol = c.qub_tol;
     return MPC_OK;
+}
+
+// How many of this process's streams the HIP runtime runs side by side.  It maps streams to
+// GPU_MAX_HW_QUEUES hardware queues (4 unless its environment said otherwise WHEN IT INITIALISED -- the
+// variable as this process sees it now may have been set too late to count), and two streams that share a
+// queue serialise: four sub-batch groups beside the caller's stream on four queues cost 259.8 ms per solve
+// against 169.8 ms for three.  So the group count is decided on what is measured here, once
+// per handle: a kernel that idles for a fixed time on the caller-side null stream and on the four group
+// streams; side by side they take one such time, sharing a queue two.
+__global__ void spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static int probe_stream_concurrency(mpc_handle *h)
+{
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+    const double spin_us = 250.0;
+    const long long ticks = (long long)(spin_us * 1e-6 * khz * 1e3);
+    hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int g = 0; g < 4; g++) {
+        if (!h->gstream[g] && hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking) != hipSuccess) return 4;
+        st[g + 1] = h->gstream[g];
+    }
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[0], 1LL);    // code object load, first-launch costs
+    if (hipDeviceSynchronize() != hipSuccess) return 4;
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 5; k++) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[k], ticks);
+        for (int k = 0; k < 5; k++) if (hipStreamSynchronize(st[k]) != hipSuccess) return 4;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        best = std::min(best, us);
+    }
+    (void)hipGetLastError();
+    // five side by side: ~ one spin (+ launch overheads); a shared queue: two spins or more
+    return best < 1.6 * spin_us ? 5 : 4;
 }
 
 extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
@@ -237,7 +279,8 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->profile = p && p[0] == '1';
     const char *gq = getenv("MPC_GROUPS");
     h->ngroups = gq ? atoi(gq) : 0;
-    if (const char *hq = getenv("GPU_MAX_HW_QUEUES")) h->hw_queues = atoi(hq);
+    // (MPC_HW_QUEUES overrides the measurement: experiments only)
+    h->hw_queues = getenv("MPC_HW_QUEUES") ? atoi(getenv("MPC_HW_QUEUES")) : probe_stream_concurrency(h);
     *out = h;
     return MPC_OK;
 }
@@ -379,7 +422,7 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
     // (tried: nblk rounded up to a multiple of 8, which puts every stage block of slot block sb and its adjoint
     // block on XCD sb % 8 so that K1c could read records from the L2 they were written to -- no change: the 13 MB
     // of records per XCD and launch pass through a 4 MB L2 long before K1c starts)
-    const size_t xy_lds = (shared && w.near.gmeta) ? sizeof(double) * 2 * (size_t)c.S : 0;
+    const size_t xy_lds = (shared && w.near.gmeta && c.S <= GRID_LDS_MAX_S) ? sizeof(double) * 2 * (size_t)c.S : 0;
     if (shared)
         hipLaunchKernelGGL((stage_kernel<MODEL, true>), dim3((unsigned)(nblk * c.N)), dim3(64), xy_lds, s, c, w, counts, nG, nC, nblk);
     else
@@ -397,10 +440,22 @@ static bool launch_eval(mpc_handle *h, const Workspace &w, hipStream_t s, const 
     return launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
 }
 
-static int check_common(mpc_handle *h, int B, const char *who)
+// Every entry point that touches the handle's tables, workspace or streams goes through here.  While an
+// asynchronous solve is posted, running or waiting to be collected (mpc_solve_batch_async .. mpc_solve_wait)
+// the worker thread owns the handle: anything else is refused BEFORE it touches the handle (a second
+// mpc_centerline_blocks would free or overwrite the search tables under the running solve's kernels).
+static int refuse_if_busy(mpc_handle *h, const char *who)
+{
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->job_posted || h->job_running || h->job_done)
+        return fail(MPC_E_ARG, std::string(who) + ": a solve of this handle is in flight (mpc_solve_wait first)");
+    return MPC_OK;
+}
+static int check_common(mpc_handle *h, int B, const char *who, bool from_worker = false)
 {
     if (!h) return fail(MPC_E_ARG, std::string(who) + ": null handle");
     if (B < 0) return fail(MPC_E_ARG, std::string(who) + ": negative batch");
+    if (!from_worker) { const int rb = refuse_if_busy(h, who); if (rb) return rb; }
     HIPCHK(hipSetDevice(h->device));
     return MPC_OK;
 }
@@ -756,6 +811,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     const long long per_iter = 700;
     long long max_rounds = per_iter * ((long long)c.max_total_inner + 16) + 8LL * c.max_outer + 1024;
     if (c.max_total_evals > 0) max_rounds = std::min(max_rounds, (long long)c.max_total_evals + per_iter + 8LL * c.max_outer + 1024);
+    if (h->round_limit > 0) max_rounds = std::min(max_rounds, h->round_limit);   // mpc_set_round_limit (test aid)
     const bool solo_ok = (h->solo_max > 0 || h->solo_all > 0) && solo_fits(h);
     size_t nev = 0;               // events 0 .. nev-1 of the pool: five per sampled launch set
     bool solo_timed[MPC_MAX_GROUPS] = {false};
@@ -792,6 +848,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         gv[ng] = group_view(w, c, ng, lo, hi);
         ng++;
     }
+    h->groups_last = ng;
     if (ng == 1) gs[0] = s;
     else {
         if (!h->gevent[MPC_MAX_GROUPS]) HIPCHK(hipEventCreateWithFlags(&h->gevent[MPC_MAX_GROUPS], hipEventDisableTiming));
@@ -880,6 +937,13 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     // (tried: the groups started 40 / 80 / 160 us apart, so that one's step kernel meets another's K1 -- no change)
     for (int g = 0; g < ng && nactive > 0; g++) queue_window(g);
     for (int g = 0; g < ng && nactive > 0; g++) if (gr[g].round < max_rounds) queue_window(g);
+    // The host has nothing to do while the windows it has queued run (milliseconds with all agents active):
+    // it spins on the event queries only for a short while after the last progress, then sleeps in short naps
+    // -- a second window is always queued behind the one polled, so a nap delays no launch -- and leaves its
+    // core to whoever needs it (eight ranks on one node are eight of these loops: INTEGRATION.md 4).
+    // MPC_SPIN=1 keeps the pure busy-wait.
+    static const bool spin_only = getenv("MPC_SPIN") != nullptr;
+    auto last_progress = std::chrono::steady_clock::now();
     while (nactive > 0 && rc_loop == MPC_OK) {
         bool progressed = false;
         for (int g = 0; g < ng; g++) {
@@ -903,7 +967,11 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             if (!go) { r.active = false; nactive--; continue; }
             queue_window(g);
         }
-        if (!progressed) __builtin_ia32_pause();
+        if (progressed) { last_progress = std::chrono::steady_clock::now(); continue; }
+        if (spin_only || std::chrono::steady_clock::now() - last_progress < std::chrono::microseconds(40))
+            __builtin_ia32_pause();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     if (rc_loop == MPC_E_LIMIT) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
     if (rc_loop != MPC_OK) return fail(rc_loop, "mpc_solve_batch: HIP error in the round loop");
@@ -929,6 +997,11 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         h->spec_issued = (int64_t)tot[4]; h->spec_used = (int64_t)tot[5];
         if (all_solo) h->solo_agents = B;
         else for (int g = 0; g < ng; g++) h->solo_agents += sctr[2 * g + 1];
+        // every agent must have reached PH_DONE: the round path says so through its request counters, the
+        // persistent kernel only through the records (its trip guard leaves an agent where it stands)
+        if (tot[6] != 0)
+            return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached (" + std::to_string(tot[6]) +
+                                     " agents unfinished in the persistent kernel)");
     }
     if (h->profile) {
         HIPCHK(hipStreamSynchronize(s));
@@ -959,11 +1032,18 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     return MPC_OK;
 }
 
+static int solve_batch_impl(mpc_handle *h, int B, const double *x0, const double *cl, const int32_t *cl_index,
+                            double *U, double *lambda, double *stats, void *stream, bool from_worker);
 extern "C" int mpc_solve_batch(mpc_handle *h, int B, const double *x0, const double *cl,
                                const int32_t *cl_index, double *U, double *lambda, double *stats,
                                void *stream)
 {
-    int rc = check_common(h, B, "mpc_solve_batch"); if (rc) return rc;
+    return solve_batch_impl(h, B, x0, cl, cl_index, U, lambda, stats, stream, false);
+}
+static int solve_batch_impl(mpc_handle *h, int B, const double *x0, const double *cl, const int32_t *cl_index,
+                            double *U, double *lambda, double *stats, void *stream, bool from_worker)
+{
+    int rc = check_common(h, B, "mpc_solve_batch", from_worker); if (rc) return rc;
     if (B == 0) return MPC_OK;
     if (!x0 || !cl || !U) return fail(MPC_E_ARG, "mpc_solve_batch: null buffer");
     const DevCfg &c = h->dc;
@@ -995,7 +1075,7 @@ static void async_worker(mpc_handle *h)
             if (!h->job_posted) return;   // quit
             j = h->job; h->job_posted = false; h->job_running = true;
         }
-        const int rc = mpc_solve_batch(h, j.B, j.x0, j.cl, j.cl_index, j.U, j.lambda, j.stats, j.stream);
+        const int rc = solve_batch_impl(h, j.B, j.x0, j.cl, j.cl_index, j.U, j.lambda, j.stats, j.stream, true);
         {
             std::lock_guard<std::mutex> lk(h->mu);
             h->job_rc = rc; h->job_err = rc ? g_err : std::string();
@@ -1109,6 +1189,7 @@ extern "C" int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *laun
 extern "C" int mpc_set_nearest_blocks(mpc_handle *h, int on)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_set_nearest_blocks: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_set_nearest_blocks"); if (rb) return rb; }
     if (on < 0 || on > 2) return fail(MPC_E_ARG, "mpc_set_nearest_blocks: mode is 0 (full scan), 1 (block boxes) or 2 (grid)");
     h->nearest_mode = on;
     return MPC_OK;
@@ -1117,13 +1198,39 @@ extern "C" int mpc_set_nearest_blocks(mpc_handle *h, int on)
 extern "C" int mpc_set_solo_max(mpc_handle *h, int max_requests)
 {
     if (!h || max_requests < 0) return fail(MPC_E_ARG, "mpc_set_solo_max: bad argument");
+    { const int rb = refuse_if_busy(h, "mpc_set_solo_max"); if (rb) return rb; }
     h->solo_max = h->solo_all = max_requests;
+    return MPC_OK;
+}
+
+extern "C" int mpc_stream_concurrency(mpc_handle *h, int *streams, int *groups_last)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_stream_concurrency: null handle");
+    if (streams) *streams = h->hw_queues;
+    if (groups_last) *groups_last = h->groups_last;
+    return MPC_OK;
+}
+
+extern "C" int mpc_set_round_limit(mpc_handle *h, int64_t rounds)
+{
+    if (!h || rounds < 0) return fail(MPC_E_ARG, "mpc_set_round_limit: bad argument");
+    { const int rb = refuse_if_busy(h, "mpc_set_round_limit"); if (rb) return rb; }
+    h->round_limit = (long long)rounds;
+    return MPC_OK;
+}
+
+extern "C" int mpc_set_memo(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_set_memo: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_set_memo"); if (rb) return rb; }
+    h->dc.no_memo = on ? 0 : 1;
     return MPC_OK;
 }
 
 extern "C" int mpc_set_groups(mpc_handle *h, int groups)
 {
     if (!h || groups < 0 || groups > MPC_MAX_GROUPS) return fail(MPC_E_ARG, "mpc_set_groups: bad argument");
+    { const int rb = refuse_if_busy(h, "mpc_set_groups"); if (rb) return rb; }
     h->ngroups = groups;
     return MPC_OK;
 }
@@ -1131,6 +1238,7 @@ extern "C" int mpc_set_groups(mpc_handle *h, int groups)
 extern "C" int mpc_set_profile(mpc_handle *h, int on)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_set_profile: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_set_profile"); if (rb) return rb; }
     h->profile = on != 0;
     return MPC_OK;
 }

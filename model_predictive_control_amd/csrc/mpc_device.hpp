@@ -26,6 +26,7 @@ struct DevCfg {
     int max_iter, max_outer, hess_heuristic, max_no_progress;
     int max_num_initial_retries, max_num_retries, max_total_num_retries, max_total_inner, max_total_evals;
     int no_spec;         // MPC_NO_SPEC: no speculative gradients (same results, more rounds)
+    int no_memo;         // MPC_NO_MEMO / mpc_set_memo(h, 0): failed retries are recomputed, not replayed (same results)
     double h;      // RK4 step Ts / nfe
     double v_ref;
     double w[6];
@@ -961,6 +962,10 @@ MPC_DEV int nearest_index_blocks(const DevCfg &c, const double *__restrict__ cl,
 // takes the full scan as a whole (uniform branch).  meta = [x0, y0, 1/cell, nx, ny, ...].
 constexpr int GRID_CELLS = 65536;   // cells per centerline row, at most
 constexpr int GRID_META = 8;        // doubles per row
+// K1b on a shared centerline keeps the row's interleaved points in LDS (16 S bytes per wave) only up to this
+// many points: 8 KB per wave leaves the kernel its three waves per SIMD; longer tables read the copy in
+// global memory (one more trip to L2 per candidate point) -- same index either way
+constexpr int GRID_LDS_MAX_S = 512;
 struct NearTab {
     const double *boxes;            // [C][NB][4]        block boxes (nearest_index_blocks), or null
     const double *gmeta;            // [C][GRID_META]    grid placement, or null

@@ -550,7 +550,7 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
     // grid search on a shared centerline: the wave keeps the row's points (1.6 KB) in LDS, so that the
     // candidate points and the three geometry points after them are LDS reads, not two more trips to L2
     extern __shared__ double2 s_xy[];
-    const bool lds_xy = SHARED_CL && w.near.gmeta != nullptr;                      // uniform; the host sizes the LDS
+    const bool lds_xy = SHARED_CL && w.near.gmeta != nullptr && c.S <= GRID_LDS_MAX_S; // uniform; the host sizes the LDS
     if (lds_xy) {
         const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(w.near.gxy);
         for (int j = threadIdx.x; j < c.S; j += 64) s_xy[j] = gp[j];

@@ -593,7 +593,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             // each, and a batch waits for the one agent that does (the Pacejka benchmark's slowest: 2 400 of
             // its 3 081 evaluations).  The memo replays the outcome and the counts, not the evaluations: the
             // result and every statistic are those of the run that was not repeated.
-            if (memo_status != 0 && m == 0 && !overwrite && c.max_total_evals == 0 &&
+            if (!c.no_memo && memo_status != 0 && m == 0 && !overwrite && c.max_total_evals == 0 &&
                 memo_iters < max_it && eps < memo_mineps) {
                 ps_status = memo_status; ps_iters = memo_iters; ps_eps = memo_eps;
                 nevals += memo_evals;
@@ -908,9 +908,9 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                 // or tolerance change repairs that, the solve ends here with the inner status (a failure
                 // at controller.py:64), U untouched.  alpaqa 0.0.1 would walk through its retries, two
                 // evaluations each, and end as MaxIter after max_outer of them -- a 2000-round straggler
-                // for the whole batch.  A NotFinite that shows up later in an inner solve (a line-search
-                // trial that overflowed and was accepted because NaN compares false, as in alpaqa) takes
-                // the ordinary not-converged path below.
+                // for the whole batch.  A NotFinite that shows up later in an inner solve (a non-finite
+                // stop measure at an iterate: a line-search trial that overflowed is a FAILED trial here,
+                // see PH_W_LS_C) takes the ordinary not-converged path below.
                 out_eps = ps_eps; out_delta = ne1;
                 status = ST_NOTFINITE;
                 outer += 1;
@@ -1105,12 +1105,17 @@ __global__ void __launch_bounds__(256) totals_kernel(const Workspace w)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     double ng = 0.0, nc = 0.0, lr = 0.0, ns = 0.0, nu = 0.0;
+    bool unfinished = false;
     if (a < w.B) {
         const double *r = w.rec + (size_t)a * REC;
         ng = r[R_NGRAD]; nc = r[R_NCOST]; lr = r[R_LBROWS]; ns = r[R_NSPEC]; nu = r[R_NSPEC_USED];
+        unfinished = r[R_PHASE] != (double)PH_DONE;
     }
     ng = wave_sum(ng); nc = wave_sum(nc); lr = wave_sum(lr); ns = wave_sum(ns); nu = wave_sum(nu);
+    const unsigned long long unf = __ballot(unfinished);
     if ((threadIdx.x & 63) == 0) {
+        // agents a solve left unfinished (the persistent kernel's trip guard ran out): the host reports MPC_E_LIMIT
+        if (unf != 0ull) atomicAdd(&w.totals[6], (unsigned long long)__popcll(unf));
         atomicAdd(&w.totals[0], (unsigned long long)ng);   // gradient evaluations executed (incl. speculative)
         atomicAdd(&w.totals[1], (unsigned long long)nc);   // cost evaluations
         atomicAdd(&w.totals[2], (unsigned long long)lr);

@@ -15,6 +15,35 @@ def shard_bounds(B, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_GATHER_OK = {}   # (backend, group id) -> bool: decided once, collectively
+
+
+def gather_supported(group=None, device=None):
+    """Does this backend build implement `gather`?  Asked ONCE per process group, by a probe every rank
+    takes part in: a one-element gather to rank 0, then an all_reduce(MIN) of "it worked here" so that all
+    ranks use the same collective from then on.  (A backend without gather refuses the call on every
+    rank alike, before anything is sent; the all_reduce makes the agreement explicit instead of assumed.)
+    Errors of the real gather later on are errors: they are raised, never mapped to another collective."""
+    key = (dist.get_backend(group), id(group))
+    if key in _GATHER_OK:
+        return _GATHER_OK[key]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = device if (on_gpu and device is not None) else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+    probe = torch.zeros(1, dtype=torch.float64, device=dev)
+    ok = 1
+    try:
+        dst_global = 0 if group is None else dist.get_global_rank(group, 0)
+        bufs = [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None
+        dist.gather(probe, gather_list=bufs, dst=dst_global, group=group)
+    except (RuntimeError, NotImplementedError):
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    _GATHER_OK[key] = bool(int(flag.item()))
+    return _GATHER_OK[key]
+
+
 def gather_controls(local, B_total, dst=0, group=None):
     """Gather row shards [b_r, k] (rank order = agent order) into [B_total, k] on rank `dst`
     (None elsewhere).  Ragged shards are padded to the largest one for the collective."""
@@ -30,15 +59,11 @@ def gather_controls(local, B_total, dst=0, group=None):
         pad = pad.cpu()   # rehearsal on one GPU box: gloo moves host tensors
     # a gather to `dst` ("no collective beyond a final gather"): every rank sends its shard
     # once, only `dst` receives -- 1/world of the bytes an all_gather would move over xGMI
-    dst_global = dst if group is None else dist.get_global_rank(group, dst)
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    try:
+    if gather_supported(group, local.device if local.is_cuda else None):
+        dst_global = dst if group is None else dist.get_global_rank(group, dst)
+        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
         dist.gather(pad, gather_list=bufs, dst=dst_global, group=group)
-    except (RuntimeError, NotImplementedError) as exc:
-        # a backend build without gather refuses the call on every rank alike, before anything is sent:
-        # the all_gather below is then the one code path all ranks take
-        if "gather" not in str(exc).lower() and "not supported" not in str(exc).lower() and "implemented" not in str(exc).lower():
-            raise
+    else:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad, group=group)
     if rank != dst:

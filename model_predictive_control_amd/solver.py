@@ -38,6 +38,8 @@ class BatchedMPC:
         h = C.c_void_p()
         _lib.check(self.lib.mpc_create(C.byref(cfg), idx, C.byref(h)))
         self._h = h
+        self._pending = False       # an asynchronous solve is in flight: the worker thread owns the handle
+        self._cl_key, self._cl_keep = None, None   # the centerline table the search tables were last built for
         import os
         # nearest-point search of K1b: 2 grid of index ranges (default), 1 block boxes, 0 the full scan
         self._nearest_blocks = 0 if "MPC_NEAREST_SCAN" in os.environ else 1 if "MPC_NEAREST_BLOCKS" in os.environ else 2
@@ -57,6 +59,12 @@ class BatchedMPC:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _free(self):
+        """Refuse a call on an engine whose asynchronous solve has not been collected -- before anything
+        touches the handle (the library refuses too; its tables and workspace belong to the worker)."""
+        if self._pending:
+            raise _lib.MpcError("a solve of this engine is in flight: call the function solve_async returned first")
+
     def _chk(self, t, shape, name, dtype=torch.float64):
         if not isinstance(t, torch.Tensor):
             raise TypeError(f"{name}: expected a torch.Tensor")
@@ -71,6 +79,7 @@ class BatchedMPC:
         return t
 
     def _centerline(self, cl, cl_index, B):
+        self._free()
         if cl.dim() == 1:
             cl = cl.unsqueeze(0)
         if cl.dim() != 2 or cl.shape[1] != 2 * self.S:
@@ -83,9 +92,21 @@ class BatchedMPC:
                 raise ValueError("cl_index out of range")
         if self._nearest_blocks:
             # f-2: the tables of the pruned nearest-point searches for this centerline table (three small
-            # kernels; redone on every call because the caller may have changed the table in place)
-            _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
+            # kernels: ~30 us for one row, but 65 536 cells x 2 (S - 1) points and 256 KB of cells PER ROW for a
+            # table of many rows).  Rebuilt only when the table is another one or has been written to since
+            # (torch counts in-place writes in `_version`; the engine keeps the tensor alive meanwhile, so its
+            # address cannot be handed to another table).  A table changed behind torch's back -- by a raw
+            # kernel on its pointer -- needs `invalidate_centerline_tables()`.
+            key = (cl.data_ptr(), tuple(cl.shape), cl._version, self._nearest_blocks)
+            if key != self._cl_key:
+                self._cl_key, self._cl_keep = None, None
+                _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
+                self._cl_key, self._cl_keep = key, cl
         return cl
+
+    def invalidate_centerline_tables(self):
+        """Forget the nearest-point search tables: the next call rebuilds them for the table it is given."""
+        self._cl_key, self._cl_keep = None, None
 
     def _empty(self, *shape, dtype=torch.float64):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -197,6 +218,7 @@ class BatchedMPC:
         """The same solve without holding the caller's thread (mpc_solve_batch_async): returns a function;
         calling it waits for the solve (mpc_solve_wait) and returns (U*, lambda*, stats).  One solve in
         flight per engine; no other call on the engine in between."""
+        self._free()
         B = x0.shape[0]
         self._chk(x0, (B, self.nx), "x0"); self._chk(U, (B, self.n), "U")
         cl = self._centerline(centerline, cl_index, B)
@@ -210,9 +232,13 @@ class BatchedMPC:
         keep = (x0, cl, cl_index, U, lam, stats)      # the buffers stay alive until the wait
         _lib.check(self.lib.mpc_solve_batch_async(self._h, B, _ptr(x0), _ptr(cl), _ptr(cl_index), _ptr(U),
                                                   _ptr(lam), _ptr(stats), self._stream()))
+        self._pending = True
 
         def wait():
-            _lib.check(self.lib.mpc_solve_wait(self._h))
+            try:
+                _lib.check(self.lib.mpc_solve_wait(self._h))
+            finally:
+                self._pending = False
             return keep[3], keep[4], keep[5]
         return wait
 
@@ -275,6 +301,23 @@ class BatchedMPC:
     def set_solo_max(self, max_requests):
         """Requests per round up to which a group finishes in the persistent wave-per-agent kernel (0 = off)."""
         _lib.check(self.lib.mpc_set_solo_max(self._h, int(max_requests)))
+
+    def set_memo(self, on=True):
+        """Failed inner solves that the outer loop backtracks over without constraints are replayed from a memo
+        (default) or recomputed (False): same controls, multipliers and statistics, fewer evaluations executed."""
+        _lib.check(self.lib.mpc_set_memo(self._h, int(bool(on))))
+
+    def set_round_limit(self, rounds):
+        """Test aid: cap on the rounds (persistent kernel: trips per agent) of a solve; a solve that does not
+        finish inside it returns MPC_E_LIMIT.  0 = the built-in guard alone."""
+        _lib.check(self.lib.mpc_set_round_limit(self._h, int(rounds)))
+
+    def stream_concurrency(self):
+        """(streams the HIP runtime runs side by side for this process -- 5 means five or more, measured when
+        the engine was created --, sub-batch groups of the last solve)."""
+        a, b = C.c_int(), C.c_int()
+        _lib.check(self.lib.mpc_stream_concurrency(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_profile(self, on=True):
         _lib.check(self.lib.mpc_set_profile(self._h, int(bool(on))))
