@@ -33,6 +33,11 @@ from model_predictive_control_amd.sharding import gather_controls, shard_bounds 
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TF = 78.6   # vendor fp64 vector peak
+# The loosest ALM/PANOC tolerance at which ALL of the first 4 096 agents of this batch have controls within
+# north_star's 1e-5 relative of the CPU oracle's (tests/dev_gpu_eps_sweep.py, profiles/r03_eps_sweep.txt; at the
+# reference's own 1e-6, controller.py:41, 87.5 % are: both solvers stop inside the same 1e-6 ball of a flat
+# problem).  The `parity_at_1e-5` leg reports the throughput there; tests/test_gpu_parity.py asserts the 100 %.
+PARITY_EPS = 1e-8
 
 
 def straight_centerline(S=100):
@@ -54,6 +59,27 @@ def synthetic_states(model, lo, hi, seed=0):
         s0, s1 = max(lo, b0), min(hi, b0 + blk)
         out[s0 - lo:s1 - lo] = chunk[s0 - b0:s1 - b0]
     return out if model == mp.MODEL_PACEJKA else out[:, :4].copy()
+
+
+def fp64_flops_per_solve(model, N, e_grad, e_cost):
+    """F = (4 E_g + E_f) 16 N C_ode per solve -- E_g gradient evaluations (forward + adjoint = 4
+    forward-rollout equivalents), E_f cost evaluations, 16 RHS evaluations per stage, C_ode flop-equivalents per
+    RHS evaluation (an fp64 transcendental counted as 20: a convention, not a count).  The nearest-point
+    search is not in it (the grid search looks at ~10 points per stage, < 1 % of a stage's work)."""
+    c_ode = 250.0 if model == mp.MODEL_PACEJKA else 120.0
+    return (4.0 * e_grad + e_cost) * 16.0 * N * c_ode, c_ode
+
+
+def timed_solves(eng, X0, cl, U0, dev, steps, warmup=1):
+    """`steps` blocking solves after `warmup`: (seconds per solve, controls, stats, info of the last)."""
+    for _ in range(warmup):
+        eng.solve(X0, cl, U0)
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(steps):
+        U, _, st = eng.solve(X0, cl, U0)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t) / steps, U, st, eng.last_solve_info()
 
 
 def cpu_baseline(args, cfg_kw, cl, U_gpu=None, st_gpu=None):
@@ -123,6 +149,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline-pass", action="store_true",
                     help="skip the untimed extra pass that solves consecutive batches on two handles side by side")
+    ap.add_argument("--no-parity-leg", action="store_true",
+                    help="skip the extra leg at the tolerance where the controls are within 1e-5 of the CPU oracle's")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Pacejka nx=6 N=12 secondary measurement")
     ap.add_argument("--no-kernel-pass", action="store_true",
                     help="skip the untimed single-group pass that measures per-kernel durations")
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event sampling inside the timed steps too")
@@ -147,6 +176,9 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if world > 1:
+        from model_predictive_control_amd.sharding import gather_supported
+        gather_supported(None, dev)     # the one-off collective capability probe, outside every timed region
     B_total = args.batch * world
     lo, hi = shard_bounds(B_total, rank, world)
     B = hi - lo
@@ -305,20 +337,26 @@ def main():
                     ent["pmc_source"] = pmc_src
                 kernels[k + "_kernel"] = ent
             dominant = max(kms, key=kms.get)
-            # fp64 work estimate for K1: 16 RHS per stage (rollout), +16 RHS with partials and
-            # NX tangent directions per stage (gradient requests), 98-point nearest scan per stage
-            c_ode = 250.0 if args.model == mp.MODEL_PACEJKA else 120.0
-            flop_k1 = per * N * (16 * c_ode + 98 * 8) + egk * N * 16 * c_ode * (1 + 0.5 * nx)
+        # fp64 work, SURVEY 8(d): F = (4 E_g + E_f) 16 N C_ode with the measured evaluation counts (executed
+        # evaluations of rank 0's shard, the speculative ones included) against the wall time of a timed step
+        # (all kernels, overlap included) -- and, on the single-group pass, against the K1 kernels' own time
+        f_step, c_ode = fp64_flops_per_solve(args.model, N, eg / B, ec / B)
+        fp64 = {"achieved": f_step * B_total / step_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                "what": "whole timed step: flops per solve x solves per step / wall time of a step",
+                "flops_per_solve": f_step, "E_g": eg / B, "E_f": ec / B, "C_ode": c_ode,
+                "flop_model": "SURVEY 8(d): F = (4 E_g + E_f) 16 N C_ode; E_g, E_f = executed gradient / cost "
+                              "evaluations per solve (measured); a transcendental counts 20 (convention)"}
+        fp64["frac"] = fp64["achieved"] / (FP64_VALU_PEAK_TF * world)
+        if kinfo:
+            kms = kinfo["kernel_ms"]
+            per = kinfo["evals_grad"] + kinfo["evals_cost"]
+            f_pass, _ = fp64_flops_per_solve(args.model, N, kinfo["evals_grad"] / B, kinfo["evals_cost"] / B)
             k1_ms = kms.get("rollout", 0) + kms.get("stage", 0) + kms.get("adjoint", 0)
-            fp64 = {"achieved": flop_k1 / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None, "peak": FP64_VALU_PEAK_TF,
-                    "unit": "TFLOP/s", "kernels": "K1a+K1b+K1c (single-group pass)",
-                    "flop_model": "16 RHS/stage + 98-pt scan; gradient: +16 RHS with NX tangents; C_ode=%g" % c_ode}
-            if fp64["achieved"]:
-                fp64["frac"] = fp64["achieved"] / FP64_VALU_PEAK_TF
-                # the same work against the wall time of a timed step (all kernels, overlap included)
-                fp64["whole_step_TFLOPs"] = flop_k1 / step_s / 1e12
-        else:
-            fp64 = None
+            if k1_ms > 0:
+                k1 = f_pass * B / (k1_ms * 1e-3) / 1e12
+                fp64["k1_only"] = {"achieved": k1, "frac": k1 / FP64_VALU_PEAK_TF, "ms_per_solve": k1_ms,
+                                   "kernels": "K1a+K1b+K1c on the single-group pass (their own time, no overlap "
+                                              "with the step kernel), same F"}
         dk = kernels.get(dominant + "_kernel") if dominant else None
         out = {
             "metric": "MPC solves/sec, bicycle model N=20 nx=4 nu=2, batch=65536; 1/2/4/8 GPU",
@@ -330,7 +368,9 @@ def main():
                        "batch_per_gpu": args.batch, "horizon": N, "nx": nx, "nu": 2, "m_c": m,
                        "lbfgs_memory": int(cfg.lbfgs_memory), "tolerance": cfg.alm_eps,
                        "max_total_inner": int(cfg.max_total_inner), "max_total_evals": int(cfg.max_total_evals),
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "hw_queues_env": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "streams_side_by_side_measured": eng.stream_concurrency()[0],
+                       "sub_batch_groups": int(infos[-1].get("groups", 0)),
                        "parallelism": f"agents sharded x{world}, no collective in the solve, final gather to rank 0"},
             "solver": {"converged_frac": conv, "inner_iters_mean": it_mean, "inner_iters_max": it_max,
                        "evals_per_solve_mean": ev_mean, "evals_per_solve_max": ev_max, "rounds": rounds,
@@ -351,7 +391,7 @@ def main():
                                      "model_frac_of_peak": (dk["model_GBps"] or 0) / HBM_PEAK_GBS,
                                      "timing": "HIP events on the solve's stream, one sub-batch group (no overlap "
                                                "with other launches), untimed extra solve"} if dk else None),
-                "fp64_valu": fp64,
+                "fp64_valu": fp64, "flops_fraction": fp64["frac"] if fp64 else None,
                 "note": "the solve is fp64-issue / latency bound, not HBM bound and not MFMA (SURVEY 8d, DESIGN.md 5)"},
             "kernels": kernels,
             "controls_sha256_first_65536": hashlib.sha256(
@@ -366,6 +406,47 @@ def main():
             base, parity = cpu_baseline(args, cfg_kw, cl_np, U.cpu().numpy(), st.cpu().numpy())
             out["cpu_baseline"] = base
             out["parity_sample"] = parity
+        # ---- reported beside the headline, never as it: the SAME batch at the loosest tolerance where north_star's
+        # parity bar (controls within 1e-5 relative of the CPU path) holds for every agent of the sample
+        if not args.no_parity_leg and world == 1 and args.model == mp.MODEL_KINEMATIC:
+            eng.set_profile(False)
+            kw = dict(cfg_kw, alm_eps=PARITY_EPS)
+            eng_p = mp.BatchedMPC(mp.default_config(args.model, N, **kw), dev)
+            sec, Up, stp, infp = timed_solves(eng_p, X0, cl, U0, dev, steps=3)
+            leg = {"alm_eps": PARITY_EPS, "value": B / sec, "unit": "solves/s", "ms_per_step": sec * 1e3, "steps": 3,
+                   "converged_frac": float((stp[:, 0] == 1).double().mean().item()),
+                   "inner_iters_mean": float(stp[:, 2].mean().item()), "rounds": infp["rounds"],
+                   "note": "same 65 536-agent batch and kernels as `value`, tolerance alm_eps tightened from the "
+                           "reference's 1e-6 (controller.py:41) to the loosest value at which every agent of the "
+                           "4 096-agent sample is within 1e-5 relative of the CPU oracle (tests/dev_gpu_eps_sweep.py)"}
+            if not args.no_cpu_baseline:
+                pargs = argparse.Namespace(**vars(args))
+                _, par = cpu_baseline(pargs, kw, cl_np, Up.cpu().numpy(), stp.cpu().numpy())
+                leg["parity_sample"] = par
+                leg["frac_dU_le_1e-5"] = par["frac_dU_le_1e-5"]
+            out["parity_at_1e-5"] = leg
+            del eng_p
+        # ---- the reference's own model (car_dynamics.py:93-129, nx = 6; main.py:67-68 N = 12) at the same batch
+        if not args.no_secondary and world == 1 and args.model == mp.MODEL_KINEMATIC:
+            Np = 12
+            eng_s = mp.BatchedMPC(mp.default_config(mp.MODEL_PACEJKA, Np), dev)
+            Xs = torch.tensor(synthetic_states(mp.MODEL_PACEJKA, lo, hi), dtype=torch.float64, device=dev)
+            Us0 = torch.tensor([1.0, 0.0], dtype=torch.float64, device=dev).repeat(B, Np)
+            sec, Us, sts, infs = timed_solves(eng_s, Xs, cl, Us0, dev, steps=2)
+            eng_s.set_profile(True)                      # one more solve with HIP events around the kernels
+            eng_s.solve(Xs, cl, Us0)
+            infk = eng_s.last_solve_info()
+            out["secondary"] = {"pacejka_nx6_N12": {
+                "workload": "%d agents/GPU, Pacejka bicycle nx=6 nu=2 (car_dynamics.py:93-129), N=12 (main.py:68), box input "
+                            "constraints, straight S=100 centerline, ALM+PANOC eps=1e-6, no evaluation budget" % B,
+                "value": B / sec, "unit": "solves/s", "ms_per_step": sec * 1e3, "steps": 2, "blocking": True,
+                "converged_frac": float((sts[:, 0] == 1).double().mean().item()),
+                "inner_iters_mean": float(sts[:, 2].mean().item()), "evals_per_solve_mean": float(sts[:, 7].mean().item()),
+                "evals_per_solve_max": float(sts[:, 7].max().item()), "rounds": infs["rounds"],
+                "solo_agents": infs["solo_agents"],
+                "solo_kernel_ms": infk["kernel_ms"]["solo"], "solo_kernel_share": infk["kernel_ms"]["solo"] / (sec * 1e3),
+                "controls_sha256": hashlib.sha256(np.ascontiguousarray(Us.cpu().numpy()).tobytes()).hexdigest()}}
+            del eng_s
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

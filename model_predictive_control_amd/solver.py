@@ -340,4 +340,4 @@ class BatchedMPC:
                 "launches": {k: int(kl[i]) for i, k in enumerate(names)}, "solo_agents": int(sa.value),
                 "rounds": r.value, "evals_grad": g.value, "evals_cost": c.value,
                 "eval_ms": e.value, "step_ms": s.value, "launch_pairs": int(lm.value), "lbfgs_rows": lr.value,
-                "spec_issued": si.value, "spec_used": su.value}
+                "spec_issued": si.value, "spec_used": su.value, "groups": self.stream_concurrency()[1]}

@@ -90,3 +90,51 @@ def test_gather_ragged_shards(tmp_path):
 
 def test_gather_with_empty_shard(tmp_path):
     _run(1, 3, tmp_path)
+
+
+def _probe_worker(rank, world, port, out_dir):
+    """The collective capability probe: asked once, the same answer on every rank; with the answer forced to
+    "no gather" every rank takes the all_gather path and the result is the same; an error inside the real
+    collective is raised, never mapped to another collective."""
+    sys.path.insert(0, ROOT)
+    from model_predictive_control_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = sharding.gather_supported()
+    assert ok is True and sharding.gather_supported() is True        # gloo implements gather; second call: cached
+    assert len(sharding._GATHER_OK) == 1
+    B, k = 11, 3
+    lo, hi = sharding.shard_bounds(B, rank, world)
+    local = torch.arange(lo * k, hi * k, dtype=torch.float64).reshape(hi - lo, k)
+    a = sharding.gather_controls(local, B, dst=0)
+    for key in list(sharding._GATHER_OK):
+        sharding._GATHER_OK[key] = False                             # a backend build without gather
+    b = sharding.gather_controls(local, B, dst=0)
+    if rank == 0:
+        assert torch.equal(a, b) and torch.equal(a, torch.arange(B * k, dtype=torch.float64).reshape(B, k))
+    else:
+        assert a is None and b is None
+    # a failure of the collective itself is an error on the rank it happens on
+    real = dist.all_gather
+    def boom(*args, **kw):
+        raise RuntimeError("gather: peer lost")                      # the text the old fallback matched on
+    dist.all_gather = boom
+    try:
+        raised = False
+        try:
+            sharding.gather_controls(local, B, dst=0)
+        except RuntimeError:
+            raised = True
+        assert raised
+    finally:
+        dist.all_gather = real
+    dist.barrier()
+    with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_gather_capability_is_probed_once_and_errors_are_raised(tmp_path):
+    port = _free_port()
+    mp.spawn(_probe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))

@@ -4,6 +4,8 @@ full batch size -- through size-independent properties (KKT residual, permutatio
 determinism, cost decrease).  Tolerances: fp64 model layer 1e-12 relative; controls 1e-5 relative
 (north_star), asserted with both solvers converged far below that.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -211,6 +213,163 @@ def test_failed_retries_are_replayed_not_recomputed(dev, O):
     assert torch.equal(Ub[777], U1[0]) and np.array_equal(sb.cpu().numpy()[777], s1[0])
 
 
+def test_memo_switch_changes_nothing_but_the_work(dev):
+    """The retry memo (mpc_solver.hpp PH_OUTER_BEGIN) is the one variant that SKIPS work: with it switched off
+    (mpc_set_memo / MPC_NO_MEMO) the failed retries are recomputed as the reference walks them.  On the slice
+    of bench.py's Pacejka batch that holds its slowest agent (48 296, twenty retries of ~120 evaluations) and
+    2 047 neighbours: controls and all eight statistics columns bit for bit the same, evaluations executed
+    strictly fewer with the memo."""
+    import bench
+    N, lo, hi = 12, 47104, 49152
+    X0 = T(bench.synthetic_states(1, lo, hi), dev)
+    cl = T(straight_centerline(), dev)
+    U0 = T(np.tile([1.0, 0.0], (hi - lo, N)), dev)
+    eng = mp.BatchedMPC(mp.default_config(1, N), dev)
+    out = []
+    for memo in (True, False, True):
+        eng.set_memo(memo)
+        U, lam, st = eng.solve(X0, cl, U0)
+        info = eng.last_solve_info()
+        out.append((U, st, info["evals_grad"] + info["evals_cost"]))
+    (U1, s1, e1), (U0_, s0, e0), (U2, s2, e2) = out
+    assert lam is None
+    assert torch.equal(U1, U0_) and torch.equal(s1, s0)           # memo on == memo off: U and all 8 stats columns
+    assert torch.equal(U2, U1) and torch.equal(s2, s1) and e2 == e1
+    assert e1 < e0, (e1, e0)                                       # and it does skip work
+    k = 48296 - lo
+    assert s1[k, 1] >= 30 and s1[k, 0] == 1                        # the stalling agent is in the slice (>= 20 retries)
+    assert e0 - e1 >= 1500                                         # ~2 400 evaluations replayed for that agent alone
+    # the environment switch is the same switch
+    import os
+    os.environ["MPC_NO_MEMO"] = "1"
+    try:
+        eng_env = mp.BatchedMPC(mp.default_config(1, N), dev)
+    finally:
+        del os.environ["MPC_NO_MEMO"]
+    U3, _, s3 = eng_env.solve(X0, cl, U0)
+    i3 = eng_env.last_solve_info()
+    assert torch.equal(U3, U1) and torch.equal(s3, s1) and i3["evals_grad"] + i3["evals_cost"] == e0
+
+
+def test_controls_within_1e5_of_oracle_at_bench_parity_tolerance(dev, O):
+    """north_star's bar -- controls within 1e-5 relative of the CPU path -- on bench.py's first 4 096 agents at
+    bench.PARITY_EPS, the tolerance of bench.py's `parity_at_1e-5` leg: EVERY agent, same status, same outer
+    iterations.  (At the reference's own eps = 1e-6 both solvers stop inside the same 1e-6 ball of a flat problem
+    and 87.5 % of these agents are within 1e-5: test_solve_reference_tolerance_statistics.)"""
+    import bench
+    N, B = 20, 4096
+    cfg, ocfg = both(O, 0, N, alm_eps=bench.PARITY_EPS)
+    X0 = bench.synthetic_states(0, 0, B)
+    cl = straight_centerline()
+    U0 = np.tile([1.0, 0.0], (B, N))
+    U, _, st = mp.BatchedMPC(cfg, dev).solve(T(X0, dev), T(cl, dev), T(U0, dev))
+    U, st = U.cpu().numpy(), st.cpu().numpy()
+    Uo, _, so = O.solve_batch(ocfg, X0, cl, U0)
+    assert (st[:, 0] == 1).all() and (so[:, 0] == 1).all()
+    d = np.abs(U - Uo).max(1) / np.maximum(1.0, np.abs(Uo).max(1))
+    assert (d <= 1e-5).all(), (d.max(), (d <= 1e-5).mean())
+    assert np.array_equal(st[:, 1], so[:, 1])
+    assert np.abs(st[:, 6] - so[:, 6]).max() <= 1e-10
+
+
+def test_round_limit_is_reported_on_both_paths(dev):
+    """A solve that does not finish inside the round limit returns MPC_E_LIMIT -- from the round loop (request
+    counters) and from the persistent kernel (whose trip guard leaves an agent where it stands: the host counts
+    the records that are not done).  mpc_set_round_limit is the test aid that makes the limit reachable."""
+    from model_predictive_control_amd import _lib
+    N = 20
+    cl = T(straight_centerline(), dev)
+    for B in (64, 9000):                                          # persistent kernel from the start / rounds
+        X0 = T(synthetic_states(0, B, seed=5), dev)
+        U0 = T(np.tile([1.0, 0.0], (B, N)), dev)
+        eng = mp.BatchedMPC(mp.default_config(0, N), dev)
+        eng.set_solo_max(100000 if B == 64 else 0)
+        Uref, _, sref = eng.solve(X0, cl, U0)
+        eng.set_round_limit(6)
+        with pytest.raises(_lib.MpcError, match="error -4"):
+            eng.solve(X0, cl, U0)
+        eng.set_round_limit(0)
+        U, _, st = eng.solve(X0, cl, U0)                          # the handle is usable afterwards
+        assert torch.equal(U, Uref) and torch.equal(st, sref)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_shared_table_with_many_points(dev, O, model):
+    """A shared centerline of S = 5 000 points (the grid search keeps the row's points in LDS only up to
+    GRID_LDS_MAX_S = 512 points, 8 KB per wave; beyond, the copy in global memory): K1 with the grid equals K1
+    with the full scan bit for bit, equals the oracle, and the solve runs (16 S bytes of LDS per wave made every
+    launch fail from S = 4 097 on)."""
+    S, N, B = 5000, 8, 130
+    th = np.linspace(0, 1.5 * np.pi, S)
+    cl_np = np.stack((20 * np.cos(th), 20 * np.sin(th) + 20), 1).ravel(order="F")   # spacing ~0.019
+    cfg, ocfg = both(O, model, N, S=S, max_total_evals=3000)      # (one agent of the batch is a 50 000-evaluation straggler)
+    rng = np.random.default_rng(2)
+    a = rng.uniform(0.05, 1.4 * np.pi, B)
+    X0 = np.zeros((B, 6))
+    X0[:, 0] = 20 * np.cos(a) + rng.uniform(-.2, .2, B); X0[:, 1] = 20 * np.sin(a) + 20 + rng.uniform(-.2, .2, B)
+    X0[:, 2] = a + np.pi / 2 + rng.uniform(-.2, .2, B); X0[:, 3] = rng.uniform(.4, 1.2, B)
+    X0 = X0 if model == 1 else X0[:, :4].copy()
+    U = np.tile([0.5, 0.02], (B, N)) + rng.uniform(-.02, .02, (B, 2 * N))
+    eng = mp.BatchedMPC(cfg, dev)
+    CL = T(cl_np, dev)
+    eng.set_nearest_blocks(2)
+    p2, g2, _ = eng.eval_cost_grad(T(X0, dev), CL, T(U, dev))
+    eng.set_nearest_blocks(0)
+    p0, g0, _ = eng.eval_cost_grad(T(X0, dev), CL, T(U, dev))
+    assert torch.equal(p2, p0) and torch.equal(g2, g0)
+    po, go = O.psi_batch(ocfg, X0, cl_np, U)
+    assert np.allclose(p2.cpu().numpy(), po, rtol=1e-11) and rel(g2.cpu().numpy(), go) <= 1e-8
+    eng.set_nearest_blocks(2)
+    for Bs in (B, 9000):                                          # persistent kernel / rounds (stage_kernel's LDS copy)
+        Xs = np.tile(X0, (Bs // B + 1, 1))[:Bs]
+        Us, _, st = eng.solve(T(Xs, dev), CL, T(np.tile([0.5, 0.0], (Bs, N)), dev))
+        assert torch.isfinite(Us).all() and (st[:, 0] == 1).float().mean() >= 0.9
+        if Bs > B:
+            assert torch.equal(Us[B:2 * B], Us[:B])               # the same agents again: same bits
+
+
+def test_switch_points_do_not_change_results(dev):
+    """The host picks kernels and sub-batch groups from the batch size and from the stream concurrency it
+    measured: the persistent kernel for whole batches up to 4 096 agents (BASELINE config 2 is exactly that
+    size), step-kernel workgroups of 4 / 16 / 64 agents, 1 / 2 / 3 / 4 groups from 16 384 / 24 576 / 49 152
+    agents (4 only when five streams run side by side).  None of it may change a bit of any agent's result:
+    700 fixed agents embedded in batches on both sides of every switch point give the same controls and the same
+    eight statistics columns, in this process (GPU_MAX_HW_QUEUES = 16 -> 4 groups at 49 152) and in a fresh child
+    process with GPU_MAX_HW_QUEUES = 4 (-> 3 groups; a child because the runtime reads the variable once)."""
+    import json, os, subprocess, sys
+    from switch_points_common import N, K_EMBED, batch, digest
+    sizes = [1024, 1025, 4096, 4097, 16384, 24576, 49152]
+    cl = T(straight_centerline(), dev)
+    eng = mp.BatchedMPC(mp.default_config(0, N), dev)
+    ref, seen = None, {}
+    for B in sizes:
+        U, _, st = eng.solve(T(batch(B), dev), cl, T(np.tile([1.0, 0.0], (B, N)), dev))
+        info = eng.last_solve_info()
+        seen[B] = (digest(U, st), info["groups"], info["solo_agents"], info["rounds"])
+        if ref is None:
+            ref = (U[:K_EMBED].clone(), st[:K_EMBED].clone())
+            assert (st[:, 0] == 1).all()
+        assert torch.equal(U[:K_EMBED], ref[0]) and torch.equal(st[:K_EMBED], ref[1]), B
+    streams, _ = eng.stream_concurrency()
+    assert seen[4096][2] == 4096 and seen[4096][3] == 0            # config 2's size: all in the persistent kernel
+    assert seen[4097][3] > 0 and seen[4097][2] < 4097              # one agent more: rounds
+    assert [seen[B][1] for B in sizes] == [1, 1, 1, 1, 2, 3, 4 if streams >= 5 else 3]
+    # the same in a fresh process whose HIP runtime has the default four hardware queues
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = subprocess.run([sys.executable, os.path.join(root, "tests", "_switch_points_child.py"), "4096", "24576", "49152"],
+                           env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert child.returncode == 0, child.stderr[-2000:]
+    rows = [json.loads(l) for l in child.stdout.splitlines() if l.startswith("{")]
+    assert [r["B"] for r in rows] == [4096, 24576, 49152]
+    for r in rows:
+        assert r["sha"] == seen[r["B"]][0], r
+        assert r["streams"] == 4                                   # measured, not read from the environment
+    assert [r["groups"] for r in rows] == [1, 3, 3]
+    if streams >= 5:
+        assert seen[49152][1] == 4                                 # and this process did use four
+
+
 def test_async_solve_is_the_same_solve(dev):
     """mpc_solve_batch_async / mpc_solve_wait (async on the given stream): the round loop on the
     handle's worker thread gives the same bits as the blocking call; two handles solve side by side; a second
@@ -226,6 +385,16 @@ def test_async_solve_is_the_same_solve(dev):
     w2 = e2.solve_async(X0[:1500], cl, U0[:1500])
     with pytest.raises(RuntimeError):
         e1.solve_async(X0, cl, U0)
+    # ... and refused BEFORE anything of the handle is touched: another centerline table would otherwise
+    # rebuild (free, reallocate, overwrite) the nearest-point tables under the running solve's kernels
+    cl_other = T(np.stack([circle_centerline(), straight_centerline()]), dev)
+    with pytest.raises(RuntimeError):
+        e1.solve_async(X0, cl_other, U0, cl_index=torch.zeros(B, dtype=torch.int32, device=dev))
+    with pytest.raises(RuntimeError):
+        e1.stage_errors(X0[:, :3].contiguous(), cl_other[0])
+    from model_predictive_control_amd import _lib
+    assert e1.lib.mpc_centerline_blocks(e1._h, C.c_void_p(cl_other.data_ptr()), 2, None) == -1   # MPC_E_ARG from the library itself
+    assert e1.lib.mpc_set_groups(e1._h, 2) == -1
     Ua, _, sa = w1()
     Ub, _, sb = w2()
     assert torch.equal(Ua, Us) and torch.equal(sa, ss)
@@ -632,17 +801,28 @@ def test_persistent_kernel_is_bit_identical(dev, model, N, B, kw):
     lane), both models, per-agent centerline rows and the ALM path."""
     from model_predictive_control_amd import bezier_curves as bc
     x0 = synthetic_states(model, B, seed=17)
-    if kw.get("constr_mode") == 1:
-        x0[:, 0] *= 3.9 / 5.0; x0[:, 3] = np.minimum(x0[:, 3], 0.65)
-    if model == 0:
-        x0[::23, 3] = 60.0                                # outside the fast ranges of the wide rollout
+    constrained = bool(kw.get("constr_mode"))
     tab = np.concatenate([straight_centerline()[None], bc.lane_change_centerlines(S=100)[:3]], 0)
     ci = (np.arange(B) % 4).astype(np.int32)
+    if constrained:
+        # starts from which the constrained problem is feasible, on the straight row (as _f4_problem and
+        # test_lane_constraint_solve_is_feasible pick them), and budgets inside which the ALM path runs to its
+        # end: the oracle converges on every one of these agents (96 / 96 and 200 / 200, at most 5 582
+        # evaluations) -- lane-change rows from arbitrary starts left 80 % of them to stop on the budget,
+        # and a test that accepts that says little about the ALM phases of the persistent kernel
+        ci[:] = 0
+        if kw["constr_mode"] == 1:
+            x0[:, 0] *= 3.9 / 5.0; x0[:, 3] = np.minimum(x0[:, 3], 0.65)
+        else:
+            x0[:, 1] = np.clip(x0[:, 1], -0.04, 0.04)
+    elif model == 0:
+        x0[::23, 3] = 60.0                                # outside the fast ranges of the wide rollout
     X0, cl, CI = T(x0, dev), T(tab, dev), T(ci, dev, torch.int32)
     U0 = T(np.tile([1., 0.], (B, N)), dev)
-    # (the evaluation budget keeps a constrained agent whose prox point overflows -- sixty doublings of
-    # L per trial -- from running for tens of thousands of rounds; it ends as MaxTime on every path)
-    cfg = mp.default_config(model, N, max_total_inner=400, max_total_evals=3000, **kw)
+    # (the evaluation budget keeps an agent whose prox point overflows -- sixty doublings of L per trial --
+    # from running for tens of thousands of rounds; it ends as MaxTime on every path)
+    budget = dict(max_total_inner=6000, max_total_evals=40000) if constrained else dict(max_total_inner=400, max_total_evals=3000)
+    cfg = mp.default_config(model, N, **budget, **kw)
     out = []
     for solo_max in (0, 100000, 64):          # rounds only / persistent kernel from the start / switch in mid-solve
         eng = mp.BatchedMPC(cfg, dev)
@@ -657,9 +837,7 @@ def test_persistent_kernel_is_bit_identical(dev, model, N, B, kw):
     for U, lam, st in ((Us, ls, ss), (Um, lm, sm)):
         assert torch.equal(U, Ur) and torch.equal(st, sr)
         assert (lam is None and lr is None) or torch.equal(lam, lr)
-    # (the constrained cases track lane-change curves from arbitrary starts inside tight budgets: most
-    # of their agents end as MaxTime -- on every path alike)
-    assert (sr[:, 0] == 1).float().mean() >= (0.15 if kw.get("constr_mode") else 0.5) and torch.isfinite(Ur).all()
+    assert (sr[:, 0] == 1).float().mean() >= (0.9 if constrained else 0.5) and torch.isfinite(Ur).all()
     assert set(sr[:, 0].unique().tolist()) <= {1.0, 2.0}
 
 

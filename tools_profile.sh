@@ -12,7 +12,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-kernel-pass --no-pipeline-pass"
+B="--no-cpu-baseline --no-kernel-pass --no-pipeline-pass --no-parity-leg --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo stats done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 $B > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
