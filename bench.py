@@ -34,10 +34,10 @@ from model_predictive_control_amd.sharding import gather_controls, shard_bounds 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TF = 78.6   # vendor fp64 vector peak
 # The loosest ALM/PANOC tolerance at which ALL of the first 4 096 agents of this batch have controls within
-# north_star's 1e-5 relative of the CPU oracle's (tests/dev_gpu_eps_sweep.py, profiles/r03_eps_sweep.txt; at the
-# reference's own 1e-6, controller.py:41, 87.5 % are: both solvers stop inside the same 1e-6 ball of a flat
-# problem).  The `parity_at_1e-5` leg reports the throughput there; tests/test_gpu_parity.py asserts the 100 %.
-PARITY_EPS = 1e-8
+# north_star's 1e-5 relative of the CPU oracle's (tests/dev_gpu_eps_sweep.py, profiles/r03_eps_sweep.txt: 1e-6 ->
+# 87.5 % of the agents, max 3.1e-5; 3e-7 -> 100 %, max 7.8e-6; 1e-7 -> max 3.3e-6; 1e-8 -> max 2.7e-7.  At the
+# reference's own 1e-6, controller.py:41, both solvers stop inside the same 1e-6 ball of a flat problem).  The `parity_at_1e-5` leg reports the throughput there; tests/test_gpu_parity.py asserts the 100 %.
+PARITY_EPS = 3e-7
 
 
 def straight_centerline(S=100):
@@ -444,7 +444,8 @@ def main():
                 "inner_iters_mean": float(sts[:, 2].mean().item()), "evals_per_solve_mean": float(sts[:, 7].mean().item()),
                 "evals_per_solve_max": float(sts[:, 7].max().item()), "rounds": infs["rounds"],
                 "solo_agents": infs["solo_agents"],
-                "solo_kernel_ms": infk["kernel_ms"]["solo"], "solo_kernel_share": infk["kernel_ms"]["solo"] / (sec * 1e3),
+                "solo_kernel_ms_longest": infk["solo_longest_ms"], "solo_kernel_share": infk["solo_longest_ms"] / (sec * 1e3),
+                "solo_kernel_ms_sum_over_groups": infk["kernel_ms"]["solo"],
                 "controls_sha256": hashlib.sha256(np.ascontiguousarray(Us.cpu().numpy()).tobytes()).hexdigest()}}
             del eng_s
         print(json.dumps(out))

@@ -197,6 +197,9 @@ int mpc_last_kernel_ms(mpc_handle *h, double *out4);
  * (either kernel), K1b stage (or fused K1b+K1c), K1c adjoint (unfused launches only), solo_kernel];
  * solo_agents = agents that finished in the persistent wave-per-agent kernel.  Any pointer may be NULL. */
 int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int64_t *solo_agents);
+/* profile mode: persistent-kernel time of the last solve -- summed over the sub-batch groups (their launches
+ * overlap in time: the sum can exceed the solve) and the longest single launch (the tail a blocking solve waits for) */
+int mpc_last_solo_ms(mpc_handle *h, double *sum_ms, double *longest_ms);
 /* A sub-batch group whose round holds at most `max_requests` evaluation requests leaves the rounds
  * and finishes in the persistent wave-per-agent kernel, and a batch of at most `max_requests` agents runs in
  * it from the start (0 = rounds only).  Defaults (measured): switch at 1024 requests; whole

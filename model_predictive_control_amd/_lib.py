@@ -46,7 +46,7 @@ EXPORTS = [
     "mpc_last_solve_info2", "mpc_math_probe", "mpc_set_groups", "mpc_last_kernel_ms", "mpc_lane_payoff",
     "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
     "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks", "mpc_set_memo",
-    "mpc_set_round_limit", "mpc_stream_concurrency",
+    "mpc_set_round_limit", "mpc_stream_concurrency", "mpc_last_solo_ms",
 ]
 
 
@@ -136,6 +136,7 @@ def load():
     L.mpc_set_nearest_blocks.argtypes = [vp, ci]
     L.mpc_set_memo.argtypes = [vp, ci]
     L.mpc_set_round_limit.argtypes = [vp, C.c_int64]
+    L.mpc_last_solo_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mpc_stream_concurrency.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for name in EXPORTS:
         if name != "mpc_last_error":

@@ -76,6 +76,7 @@ struct mpc_handle {
     double kernel_ms[5] = {0, 0, 0, 0, 0}; // step, K1a rollout, K1b stage, K1c adjoint, solo (profile mode)
     int64_t kernel_launches[5] = {0, 0, 0, 0, 0};
     int64_t solo_agents = 0;    // agents finished by the persistent kernel in the last solve
+    double solo_longest_ms = 0.0; // profile mode: the longest of the groups' persistent-kernel launches
     int64_t spec_issued = 0, spec_used = 0; // speculative channel-2 gradients of the last solve
     int64_t lbfgs_rows = 0; // history pairs read by K3 (each is read twice: 4*n*8 bytes per pair)
     std::vector<hipEvent_t> ev_pool;
@@ -1016,10 +1017,12 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         const double sampled = (double)(nev / 5);
         const double scale = sampled > 0 ? (double)launch_sets / sampled : 0.0;
         for (int k = 0; k < 4; k++) h->kernel_ms[k] *= scale;
+        h->solo_longest_ms = 0.0;
         for (int g = 0; g < MPC_MAX_GROUPS; g++) {
             float d = 0.f;
             if (solo_timed[g]) (void)hipEventElapsedTime(&d, h->soloev[g][0], h->soloev[g][1]);
-            h->kernel_ms[4] += d;
+            h->kernel_ms[4] += d;                       // summed over the groups (their launches overlap in time)
+            h->solo_longest_ms = std::max(h->solo_longest_ms, (double)d);
         }
         h->step_ms = h->kernel_ms[0];
         h->eval_ms = h->kernel_ms[1] + h->kernel_ms[2] + h->kernel_ms[3];
@@ -1200,6 +1203,14 @@ extern "C" int mpc_set_solo_max(mpc_handle *h, int max_requests)
     if (!h || max_requests < 0) return fail(MPC_E_ARG, "mpc_set_solo_max: bad argument");
     { const int rb = refuse_if_busy(h, "mpc_set_solo_max"); if (rb) return rb; }
     h->solo_max = h->solo_all = max_requests;
+    return MPC_OK;
+}
+
+extern "C" int mpc_last_solo_ms(mpc_handle *h, double *sum_ms, double *longest_ms)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_last_solo_ms: null handle");
+    if (sum_ms) *sum_ms = h->kernel_ms[4];
+    if (longest_ms) *longest_ms = h->solo_longest_ms;
     return MPC_OK;
 }
 

@@ -335,9 +335,12 @@ class BatchedMPC:
         kl = (C.c_int64 * 5)()
         sa = C.c_int64()
         _lib.check(self.lib.mpc_last_kernel_profile(self._h, km, kl, C.byref(sa)))
+        ssum, slong = C.c_double(), C.c_double()
+        _lib.check(self.lib.mpc_last_solo_ms(self._h, C.byref(ssum), C.byref(slong)))
         names = ("step", "rollout", "stage", "adjoint", "solo")
         return {"kernel_ms": {k: km[i] for i, k in enumerate(names)},
                 "launches": {k: int(kl[i]) for i, k in enumerate(names)}, "solo_agents": int(sa.value),
                 "rounds": r.value, "evals_grad": g.value, "evals_cost": c.value,
                 "eval_ms": e.value, "step_ms": s.value, "launch_pairs": int(lm.value), "lbfgs_rows": lr.value,
-                "spec_issued": si.value, "spec_used": su.value, "groups": self.stream_concurrency()[1]}
+                "spec_issued": si.value, "spec_used": su.value, "groups": self.stream_concurrency()[1],
+                "solo_longest_ms": slong.value}

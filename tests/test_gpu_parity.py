@@ -680,7 +680,13 @@ def test_evaluation_budget_matches_oracle(dev, O):
     assert np.all(np.maximum(st[differ, 7], sto[differ, 7]) >= 0.8 * budget)
     assert st[:, 7].max() <= budget + 40 and sto[:, 7].max() <= budget + 40
     same = (st[:, 2] == sto[:, 2]) & (st[:, 0] == sto[:, 0])
-    assert same.mean() >= 0.3      # Pacejka paths split easily; half the agents take identical paths
+    # Identical paths (same status AND same inner-iteration count): 50.2 % of this batch, measured
+    # (profiles/r03_identical_paths.txt; 47.7 % without the budget, 58 % on the kinematic model with a budget).
+    # The two implementations round differently (lean minimax sin/cos/atan vs glibc, explicit fma vs gcc's
+    # contraction, tree vs sequential sums), and one flipped line-search or descent-lemma comparison anywhere
+    # in ~75 iterations changes the count; what must NOT happen is a systematic difference, which the
+    # evaluation-count and mean checks below would show.  The floor sits 10 points under the measurement.
+    assert same.mean() >= 0.4
     # evaluation counts: the same for most agents (a rounding-level difference can add or drop a
     # line-search backtrack on the Pacejka model), and the same on average
     assert np.mean(st[same, 7] == sto[same, 7]) >= 0.8
