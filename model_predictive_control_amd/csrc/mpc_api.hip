@@ -185,6 +185,9 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.max_total_evals = c.max_total_evals;
     d.no_spec = getenv("MPC_NO_SPEC") != nullptr;
     d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
+    d.all_rows = getenv("MPC_ALL_ROWS") != nullptr;
+    d.dbg = getenv("MPC_DBG") ? atoi(getenv("MPC_DBG")) : 0;
+    d.chain = getenv("MPC_NO_CHAIN") == nullptr && 2 * c.N <= 64;
     d.h = c.Ts / c.nfe; d.v_ref = c.v_ref;
     for (int i = 0; i < 6; i++) { d.w[i] = c.cost_w[i]; d.g_off[i] = c.g_off[i]; d.D_lb[i] = c.D_lb[i]; d.D_ub[i] = c.D_ub[i]; }
     d.lf = c.veh[1]; d.lr = c.veh[2]; d.mass = c.veh[7]; d.inv_mass = 1.0 / c.veh[7]; d.inv_iz = 1.0 / c.veh[8];
@@ -268,6 +271,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->cfg = *cfg;
     int rc = make_devcfg(*cfg, h->dc);
     if (rc) { delete h; return rc; }
+    if (h->arrive_adjoint) h->dc.chain = 0;   // (the experimental K1c-inside-K1b variant does not carry the chained step)
     h->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) {
@@ -371,7 +375,8 @@ static inline dim3 grid_for(int B, int block) { return dim3((unsigned)((B + bloc
 
 template <int MODEL>
 static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
-                          int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1)
+                          int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1,
+                          int *lists_next = nullptr, int *counts_next = nullptr)
 {
     const DevCfg &c = h->dc;
     const bool shared = w.cl_index == nullptr;
@@ -414,9 +419,9 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         const int gb = (nblk * 64 + spb - 1) / spb;
         const size_t flds = sizeof(double) * (size_t)(JS + 1) * c.N * spb;
         if (shared)
-            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, true>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC);
+            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, true>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC, lists_next, counts_next);
         else
-            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, false>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC);
+            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, false>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC, lists_next, counts_next);
         if (evb) (void)hipEventRecord(evb, s);
         return true;
     }
@@ -430,15 +435,16 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         hipLaunchKernelGGL((stage_kernel<MODEL, false>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
     if (evb) (void)hipEventRecord(evb, s);
     if (w.arrive) return true;               // K1c ran inside K1b (last-arriving stage block)
-    hipLaunchKernelGGL((adjoint_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), 0, s, c, w, counts, nG, nC);
+    hipLaunchKernelGGL((adjoint_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), 0, s, c, w, counts, nG, nC, lists_next, counts_next);
     return false;
 }
 // returns true when K1b and K1c ran as one launch
 static bool launch_eval(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
-                        int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1)
+                        int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1,
+                        int *lists_next = nullptr, int *counts_next = nullptr)
 {
-    if (h->dc.model == PAC) return launch_eval_t<PAC>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
-    return launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound);
+    if (h->dc.model == PAC) return launch_eval_t<PAC>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound, lists_next, counts_next);
+    return launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound, lists_next, counts_next);
 }
 
 // Every entry point that touches the handle's tables, workspace or streams goes through here.  While an
@@ -902,7 +908,9 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             if (ev[0]) (void)hipEventRecord(ev[0], gs[g]);
             launch_step(h, v, gs[g], lists, counts, counts_next);
             if (ev[1]) (void)hipEventRecord(ev[1], gs[g]);
-            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], r.slot_bound);
+            // (the NEXT round's lists: K1c queues the follow-up of a chained gradient request there itself)
+            int *lists_next = v.lists + (size_t)(cur ^ 1) * 2 * v.Ls;
+            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], r.slot_bound, lists_next, counts_next);
             if (ev[4]) (void)hipEventRecord(ev[4], gs[g]);
             r.round++;
             rounds_done[g]++;

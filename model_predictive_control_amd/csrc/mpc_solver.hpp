@@ -35,11 +35,20 @@ enum Phase {
 };
 enum { ST_UNKNOWN = 0, ST_CONVERGED = 1, ST_MAXTIME = 2, ST_MAXITER = 3, ST_NOTFINITE = 4,
        ST_NOPROGRESS = 5 };
-enum { REQ_NONE = 0, REQ_GRAD = 1, REQ_COST = 2, REQ_SPEC = 4 }; // bit set; SPEC = gradient on channel 2
-// a work-list entry is the agent id, plus this bit when the evaluation runs on the speculative
-// channel (input row xe2, gradient row ge2, nothing else written)
+enum { REQ_NONE = 0, REQ_GRAD = 1, REQ_COST = 2, REQ_SPEC = 4, // bit set; SPEC = gradient on channel 2
+       REQ_CHAIN = 8 };  // with REQ_GRAD: the gradient at a line-search trial point, whose follow-up K1c may run itself
+// a work-list entry is the agent id, plus CH2_BIT when the evaluation runs on the speculative
+// channel (input row xe2, gradient row ge2, nothing else written), plus CHAIN_BIT:
+//   on the gradient list: the gradient at a line-search trial point (PH_LS_TRIAL -> PH_W_LS_G).  What the agent
+//     does with it is fixed and elementwise -- prox step at the trial point, request the cost there, speculate
+//     (PH_W_LS_G) -- so the evaluation's last kernel does it, one THREAD per agent (chain_ls_g in mpc_eval.hpp),
+//     and queues the follow-up requests on the next round's lists itself: the agent skips the step kernel
+//     for a round (its phase word carries PH_INFLIGHT meanwhile), a third of all agent-steps;
+//   on the cost list: such a queued cost request -- K1c clears PH_INFLIGHT when it has served it.
 constexpr int CH2_BIT = 1 << 30;
-constexpr int AGENT_MASK = CH2_BIT - 1;
+constexpr int CHAIN_BIT = 1 << 29;
+constexpr int AGENT_MASK = CHAIN_BIT - 1;
+constexpr int PH_INFLIGHT = 64;   // added to the phase word of an agent whose next evaluation is already queued
 
 struct Workspace {
     const double *x0;                              // [B][nx]   caller's buffer
@@ -147,6 +156,13 @@ __device__ __forceinline__ double fast_rcp(double x)
     r = fma(r, fma(-x, r, 1.0), r);
     r = fma(r, fma(-x, r, 1.0), r);
     return r;
+}
+// finite-difference step of the Hessian-vector products: cbrt(eps) (1 + ||x||); one function for every place
+// that forms it (the state machine, the speculation, K1c's chained step) so that they agree bit for bit
+__device__ __forceinline__ double fd_step(double xx)
+{
+#pragma clang fp contract(off)
+    return cbrt(DBL_EPSILON) * (1.0 + sqrt(xx));
 }
 #ifdef MPC_SCAN_SUM
 __device__ __forceinline__ void wave_sum2(double &a, double &b)
@@ -439,25 +455,44 @@ __device__ __forceinline__ void update_penalty(const DevCfg &c, const Workspace 
 // what a step needs from memory before it can decide anything: the scalar record and the five rows
 // nearly every phase touches.  Loaded one agent ahead (software pipelining across the agents a wave
 // walks), so the memory round trip of agent i+1 overlaps the work of agent i.
-template <int NE> struct AgentIn { double rv; Row<NE> X, G, GE, Q, XN, GE2; };
+template <int NE> struct AgentIn { double rv; Row<NE> X, G, GE, Q, XN, GE2; bool has_q; };
 
+// `ph` = the phase the agent waits in (wave-uniform; the step kernel has it from its one look at the
+// workgroup's phase words) selects the rows that phase -- and the chain of internal phases behind it -- reads:
+//   W_LS_G  xn, ge                      (prox step at the trial point, speculation)
+//   W_LS_C  xk, gk, xn, ge, ge2         (accept: L-BFGS pair, next direction; q only if the trial FAILS: re-read there)
+//   W_HESS  xk, gk, ge, q               W_INIT_H  xk, ge          W_INIT_X  xk, ge, q
+//   W_DL, W_HEUR  xk, gk, ge, ge2       OUTER_BEGIN  nothing (it reads the caller's U itself)
+// Rows not fetched are zeros.  ph < 0 (the persistent kernel, which learns the phase from the record it
+// loads here): all of them.  Fetching six rows whatever the phase was 2.4 KB per agent-step; 1.6 KB on average now.
 template <int NE>
-__device__ __forceinline__ AgentIn<NE> load_agent(const DevCfg &c, const Workspace &w, int a, int lane)
+__device__ __forceinline__ AgentIn<NE> load_agent(const DevCfg &c, const Workspace &w, int a, int lane, int ph = -1)
 {
     AgentIn<NE> in;
     const int n = c.n;
     const size_t an = (size_t)a * n;
     in.rv = w.rec[(size_t)a * REC + lane];
-    in.X = ldrow<NE>(w.xk + an, n, lane); in.G = ldrow<NE>(w.gk + an, n, lane);
-    in.GE = ldrow<NE>(w.ge + an, n, lane); in.Q = ldrow<NE>(w.q + an, n, lane);
-    in.XN = ldrow<NE>(w.xn + an, n, lane);
-    in.GE2 = ldrow<NE>(w.ge2 + an, n, lane);
+    const bool all = ph < 0;
+    const bool nX = all || (ph != PH_W_LS_G && ph != PH_OUTER_BEGIN);
+    const bool nG = all || ph == PH_W_LS_C || ph == PH_W_HESS || ph == PH_W_DL || ph == PH_W_HEUR;
+    const bool nGE = all || ph != PH_OUTER_BEGIN;
+    const bool nQ = all || ph == PH_W_HESS || ph == PH_W_INIT_X;
+    const bool nXN = all || ph == PH_W_LS_G || ph == PH_W_LS_C;
+    const bool nGE2 = all || ph == PH_W_LS_C || ph == PH_W_DL || ph == PH_W_HEUR;
+    Row<NE> z;
+#pragma unroll
+    for (int e = 0; e < NE; e++) z.v[e] = 0.0;
+    in.X = nX ? ldrow<NE>(w.xk + an, n, lane) : z; in.G = nG ? ldrow<NE>(w.gk + an, n, lane) : z;
+    in.GE = nGE ? ldrow<NE>(w.ge + an, n, lane) : z; in.Q = nQ ? ldrow<NE>(w.q + an, n, lane) : z;
+    in.XN = nXN ? ldrow<NE>(w.xn + an, n, lane) : z;
+    in.GE2 = nGE2 ? ldrow<NE>(w.ge2 + an, n, lane) : z;
+    in.has_q = nQ;
     return in;
 }
 
 template <int NE, int MC>
 __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lane, const AgentIn<NE> &in,
-                             double *hist, bool hist_ready, bool allow_spec = true)
+                             double *hist, bool hist_ready, bool allow_spec = true, bool allow_chain = false)
 {
 #pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     const int n = c.n, m = c.m;
@@ -557,7 +592,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
         const int nj = (int)cntJ;
         spec = 0;
         if (nj > 0 && nj < n) {
-            const double h = cbrt(DBL_EPSILON) * (1.0 + sqrt(xx));
+            const double h = fd_step(xx);
             Row<NE> xh;
 #pragma unroll
             for (int e = 0; e < NE; e++) xh.v[e] = XN.v[e] + h * qv.v[e];
@@ -670,7 +705,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                 double s = 0.0;
 #pragma unroll
                 for (int e = 0; e < NE; e++) s += x.v[e] * x.v[e];
-                const double h = cbrt(DBL_EPSILON) * (1.0 + sqrt(wave_sum_n(s, n)));
+                const double h = fd_step(wave_sum_n(s, n));
                 Row<NE> xh;
 #pragma unroll
                 for (int e = 0; e < NE; e++) xh.v[e] = x.v[e] + h * g.v[e];
@@ -757,7 +792,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                     Q = qv;
                     if (nJ > 0) {
                         // Hessian-vector product of the active part by finite differences
-                        const double h = cbrt(DBL_EPSILON) * (1.0 + sqrt(xx));
+                        const double h = fd_step(xx);
                         Row<NE> xh;
 #pragma unroll
                         for (int e = 0; e < NE; e++) xh.v[e] = x.v[e] + h * qv.v[e];
@@ -834,7 +869,8 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             }
             XN = x;
             strow<NE>(w.xn + an, n, lane, x); strow<NE>(w.xe + an, n, lane, x);
-            req = REQ_GRAD; phase = PH_W_LS_G;
+            // (round path: K1c runs PH_W_LS_G for this agent right behind the gradient, see CHAIN_BIT)
+            req = REQ_GRAD | (allow_chain && c.chain ? REQ_CHAIN : 0); phase = PH_W_LS_G;
         } break;
         case PH_W_LS_G: {
             psin = fallback ? (double)psixh : (double)psie;
@@ -860,7 +896,11 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             tau /= 2.0;
             // (written so that a NaN condition -- a trial point whose evaluation overflowed -- counts as a
             // failed trial like +inf does, instead of being accepted because NaN compares false)
-            if (!(ls_cond <= margin) && tau >= c.tau_min) { phase = PH_LS_TRIAL; spec = 0; break; }
+            if (!(ls_cond <= margin) && tau >= c.tau_min) {
+                // (the direction is not among the rows fetched for this phase: a failed trial is the rare case)
+                if (!in.has_q) Q = ldrow<NE>(w.q + an, n, lane);
+                phase = PH_LS_TRIAL; spec = 0; break;
+            }
             // accept x+ : L-BFGS update with (x+ - x, grad+ - grad)
             if (gamma != gamman) { lidx = 0; lfull = 0; }
             {
@@ -1008,7 +1048,9 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     // find out that an agent is finished.
     const int base = blockIdx.x * apb;
     const double phw = lane < apb && base + lane < w.B ? w.rec[(size_t)(base + lane) * REC + R_PHASE] : 0.0;
-    const unsigned long long act = __ballot(phw != 0.0);  // PH_DONE == 0
+    // (PH_DONE == 0; an agent whose next evaluation K1c has already queued -- PH_INFLIGHT -- has nothing to do here)
+    const bool runnable = phw != 0.0 && phw < (double)PH_INFLIGHT;
+    const unsigned long long act = __ballot(runnable);
     const int rank = __popcll(act & ((1ull << lane) - 1ull));
     const int nact = __popcll(act);
     if (threadIdx.x == 0) s_next = 0;
@@ -1022,16 +1064,18 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
         if (lane == 0) i = atomicAdd(&s_next, 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= nact) return -1;
-        return (int)__builtin_ctzll(__ballot(phw != 0.0 && rank == i));
+        return (int)__builtin_ctzll(__ballot(runnable && rank == i));
     };
     AgentIn<NE> nxt;
     int loc = claim();
-    if (loc >= 0) nxt = load_agent<NE>(c, w, base + loc, lane);
+    // (MPC_ALL_ROWS: the six-row fetch of rounds 1 - 2, for the A/B measurement and the bit-identity test)
+    const auto phase_of = [&](int l) { return c.all_rows ? -1 : (int)rdlane(phw, l); };
+    if (loc >= 0) nxt = load_agent<NE>(c, w, base + loc, lane, phase_of(loc));
     while (loc >= 0) {
         const int a = base + loc;
         const AgentIn<NE> cur = nxt;
         const int loc_next = claim();
-        if (loc_next >= 0) nxt = load_agent<NE>(c, w, base + loc_next, lane); // in flight during agent a
+        if (loc_next >= 0) nxt = load_agent<NE>(c, w, base + loc_next, lane, phase_of(loc_next)); // in flight during agent a
         bool hist_ready = false;
         if (MC < 0) {
             // An agent that comes back from its Hessian-vector evaluation (or from the cost of a trial
@@ -1049,7 +1093,7 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
                 hist_ready = true;
             }
         }
-        const int req = advance_agent<NE, MC>(c, w, a, lane, cur, hist, hist_ready);
+        const int req = advance_agent<NE, MC>(c, w, a, lane, cur, hist, hist_ready, true, /*allow_chain=*/true);
         if (lane == 0) s_req[loc] = req;
         loc = loc_next;
     }
@@ -1067,7 +1111,7 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
             base = __builtin_amdgcn_readfirstlane(base);
             if (on) {
                 const int off = __popcll(bal & ((1ull << lane) - 1ull));
-                const int flag = kind == 0 && (r & REQ_SPEC) ? CH2_BIT : 0;
+                const int flag = kind == 0 ? ((r & REQ_SPEC) ? CH2_BIT : 0) | ((r & REQ_CHAIN) ? CHAIN_BIT : 0) : 0;
                 lists_out[(size_t)kind * w.Ls + base + off] = (blockIdx.x * apb + lane) | flag;
             }
         }

@@ -465,6 +465,7 @@ typedef struct {
     const double *x0, *cl;
     int n, m;
     long n_evals; /* psi/grad evaluations (statistics) */
+    int in_ls;    /* diagnostics: inside a line-search trial */
 } prob_t;
 
 static double dot(const double *a, const double *b, int n)
@@ -557,6 +558,13 @@ static int lbfgs_apply_masked(lbfgs_t *l, double *q, const double *mask)
 
 typedef struct { int status; int iters; double eps; double psi_hat; int wrote; } inner_stats;
 
+/* diagnostics of the last orc_solve on this thread (orc_last_ls_counters): where the evaluations of a solve
+ * go -- [0] line-search trials, [1] iterations, [2] descent-lemma doublings inside line-search trials,
+ * [3] descent-lemma doublings at the top of an iteration, [4] longest run of doublings in one call,
+ * [5] Hessian-vector evaluations, [6] iterations whose line search fell back to tau < tau_min */
+static __thread double g_lsc[8];
+void orc_last_ls_counters(double *out) { memcpy(out, g_lsc, sizeof g_lsc); }
+
 static double eval_psi(prob_t *P, const double *x, const double *y, const double *Sig, double *grad,
                        double *yhat)
 {
@@ -571,8 +579,10 @@ static void descent_lemma(prob_t *P, const double *y, const double *Sig, const d
 {
     const orc_config *c = P->c;
     double margin = (1.0 + fabs(psik)) * c->qub_tol;
+    int run = 0;
     while (*psixh - psik > *gp + 0.5 * (*L) * (*pp) + margin) {
         if (!((*L) * 2.0 <= c->L_max)) break;
+        g_lsc[P->in_ls ? 2 : 3] += 1; if (++run > g_lsc[4]) g_lsc[4] = run;
         *L *= 2.0; *gamma /= 2.0;
         calc_xhat(P, *gamma, xk, gk, xh, p);
         *gp = dot(gk, p, P->n);
@@ -588,6 +598,7 @@ static void hess_prod_fd(prob_t *P, const double *y, const double *Sig, const do
     const int n = P->n;
     double h = cbrt(DBL_EPSILON) * (1.0 + sqrt(dot(xk, xk, n)));
     for (int i = 0; i < n; i++) work[i] = xk[i] + h * v[i];
+    g_lsc[5] += 1;
     eval_psi(P, work, y, Sig, Hv, NULL);
     for (int i = 0; i < n; i++) Hv[i] = (Hv[i] - gk[i]) / h;
 }
@@ -715,9 +726,12 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
             else if (nJ == 0) tau = 0.0;
         }
         double phin, psin, psixhn, gpn, ppn, Ln, gamman, ls_cond;
+        g_lsc[1] += 1; P->in_ls = 1;
         do {
+            g_lsc[0] += 1;
             Ln = Lk; gamman = gamma;
             if (tau / 2.0 < c->tau_min) {
+                g_lsc[6] += 1;
                 memcpy(xn, xh, n * sizeof(double));
                 psin = psixh;
                 eval_psi(P, xn, y, Sig, gn, NULL); /* calc_grad_psi_from_yhat */
@@ -737,6 +751,7 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
             /* a NaN condition (the trial point's evaluation overflowed) is a failed trial, like +inf:
              * alpaqa's literal `ls_cond > margin` would accept it because NaN compares false */
         } while (!(ls_cond <= margin) && tau >= c->tau_min);
+        P->in_ls = 0;
 
         if (gamma != gamman) lbfgs_reset(lb);
         lbfgs_update(lb, xk, xn, gk, gn);
@@ -796,7 +811,8 @@ int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, do
 void orc_solve(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                double *stats)
 {
-    prob_t P = {c, x0, cl, 2 * c->N, orc_m(c), 0};
+    prob_t P = {c, x0, cl, 2 * c->N, orc_m(c), 0, 0};
+    memset(g_lsc, 0, sizeof g_lsc);
     const int n = P.n, m = P.m, mm = m ? m : 1;
     const int M = c->lbfgs_memory;
     double *wk = (double *)malloc(sizeof(double) * (12 * (size_t)n + 2 * mm));

@@ -115,6 +115,10 @@ void orc_psi_batch(const orc_config *c, int B, const double *x0, const double *c
                    const int32_t *cl_index, const double *U, const double *y, const double *Sigma,
                    double *psi, double *grad, int nthreads);
 int orc_max_threads(void);
+/* diagnostics of the last orc_solve on the calling thread: out[8] = [line-search trials, iterations,
+ * descent-lemma doublings inside trials, doublings at the top of an iteration, longest run of doublings,
+ * Hessian-vector evaluations, iterations that reached the safe step tau < tau_min, 0] */
+void orc_last_ls_counters(double *out);
 
 /* f-3: lane-change payoffs (game_theory.py:115-244).  params[15] = [L, W, l, theta_max, tlc, td, ti, tau,
  * a_max, h, Lf, q1, q2, a, b]; ego [B][3] = (x, v, lane); cars [B][K][3]; ncars [B] (<= K).

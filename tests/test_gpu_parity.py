@@ -328,6 +328,46 @@ def test_shared_table_with_many_points(dev, O, model):
             assert torch.equal(Us[B:2 * B], Us[:B])               # the same agents again: same bits
 
 
+@pytest.mark.parametrize("model,N,B,kw", [
+    (0, 20, 9000, {}), (1, 12, 3000, {}), (0, 20, 700, {}), (0, 7, 5000, {}),
+    (0, 12, 2500, dict(constr_mode=2, lane_halfwidth=0.05, max_total_inner=3000)),
+    (0, 40, 1500, dict(max_total_inner=400))])
+def test_chained_step_and_selective_loads_are_bit_identical(dev, monkeypatch, model, N, B, kw):
+    """Round 3's two changes to the round path against the path of rounds 1 - 2, on whole solves: (1) K1c runs
+    PH_W_LS_G for the gradient of a line-search trial point by one THREAD per agent (prox step, ||p||^2 and grad'p
+    as the same balanced trees the wavefront reductions form, speculation) and queues the follow-up requests
+    itself, the agent skipping a step kernel (MPC_NO_CHAIN: the step kernel does it); (2) the step kernel
+    fetches only the rows the agent's phase reads (MPC_ALL_ROWS: all six).  Same controls, multipliers and all
+    eight statistics columns, bit for bit -- with the persistent kernel taking over in mid-solve (agents whose
+    chained evaluation is still queued), from the start, and never; with and without speculation; with
+    constraints (m > 0); and for n = 80, where the chain is off by itself (two elements per lane)."""
+    x0 = synthetic_states(model, B, seed=23)
+    if kw.get("constr_mode") == 2:
+        x0[:, 1] = np.clip(x0[:, 1], -0.04, 0.04)
+    X0, cl = T(x0, dev), T(straight_centerline(), dev)
+    U0 = T(np.tile([1., 0.], (B, N)), dev)
+    cfg = mp.default_config(model, N, **kw)
+
+    def run(env, solo_max=None):
+        for k in ("MPC_NO_CHAIN", "MPC_ALL_ROWS", "MPC_NO_SPEC"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        eng = mp.BatchedMPC(cfg, dev)
+        if solo_max is not None:
+            eng.set_solo_max(solo_max)
+        U, lam, st = eng.solve(X0, cl, U0)
+        return U, lam, st, eng.last_solve_info()
+
+    Ur, lr, sr, ir = run(("MPC_NO_CHAIN", "MPC_ALL_ROWS"))        # the round path of rounds 1 - 2
+    assert (sr[:, 0] == 1).float().mean() >= 0.9
+    for env, solo_max in (((), None), ((), 0), ((), 100000), (("MPC_NO_CHAIN",), None), (("MPC_ALL_ROWS",), None),
+                          (("MPC_NO_SPEC",), None), (("MPC_NO_SPEC",), 0)):
+        U, lam, st, info = run(env, solo_max)
+        assert torch.equal(U, Ur) and torch.equal(st, sr), (env, solo_max)
+        assert (lam is None and lr is None) or torch.equal(lam, lr)
+
+
 def test_switch_points_do_not_change_results(dev):
     """The host picks kernels and sub-batch groups from the batch size and from the stream concurrency it
     measured: the persistent kernel for whole batches up to 4 096 agents (BASELINE config 2 is exactly that
