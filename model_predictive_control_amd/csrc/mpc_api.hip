@@ -186,7 +186,6 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.no_spec = getenv("MPC_NO_SPEC") != nullptr;
     d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
     d.all_rows = getenv("MPC_ALL_ROWS") != nullptr;
-    d.dbg = getenv("MPC_DBG") ? atoi(getenv("MPC_DBG")) : 0;
     d.chain = getenv("MPC_NO_CHAIN") == nullptr && 2 * c.N <= 64;
     d.h = c.Ts / c.nfe; d.v_ref = c.v_ref;
     for (int i = 0; i < 6; i++) { d.w[i] = c.cost_w[i]; d.g_off[i] = c.g_off[i]; d.D_lb[i] = c.D_lb[i]; d.D_ub[i] = c.D_ub[i]; }
@@ -271,7 +270,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     h->cfg = *cfg;
     int rc = make_devcfg(*cfg, h->dc);
     if (rc) { delete h; return rc; }
-    if (h->arrive_adjoint) h->dc.chain = 0;   // (the experimental K1c-inside-K1b variant does not carry the chained step)
+    if (h->arrive_adjoint) h->dc.chain = 0;   // (the experimental K1c-inside-K1b variant leaves no gradient-slot count for chain_block)
     h->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) {
@@ -376,7 +375,7 @@ static inline dim3 grid_for(int B, int block) { return dim3((unsigned)((B + bloc
 template <int MODEL>
 static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
                           int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1,
-                          int *lists_next = nullptr, int *counts_next = nullptr)
+                          int *desc = nullptr)
 {
     const DevCfg &c = h->dc;
     const bool shared = w.cl_index == nullptr;
@@ -419,9 +418,9 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         const int gb = (nblk * 64 + spb - 1) / spb;
         const size_t flds = sizeof(double) * (size_t)(JS + 1) * c.N * spb;
         if (shared)
-            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, true>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC, lists_next, counts_next);
+            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, true>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC, desc);
         else
-            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, false>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC, lists_next, counts_next);
+            hipLaunchKernelGGL((stage_adjoint_kernel<MODEL, false>), dim3((unsigned)gb), dim3(BLK), flds, s, c, w, counts, nG, nC, desc);
         if (evb) (void)hipEventRecord(evb, s);
         return true;
     }
@@ -435,16 +434,16 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
         hipLaunchKernelGGL((stage_kernel<MODEL, false>), dim3((unsigned)(nblk * c.N)), dim3(64), 0, s, c, w, counts, nG, nC, nblk);
     if (evb) (void)hipEventRecord(evb, s);
     if (w.arrive) return true;               // K1c ran inside K1b (last-arriving stage block)
-    hipLaunchKernelGGL((adjoint_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), 0, s, c, w, counts, nG, nC, lists_next, counts_next);
+    hipLaunchKernelGGL((adjoint_kernel<MODEL>), dim3((unsigned)nblk), dim3(64), 0, s, c, w, counts, nG, nC, desc);
     return false;
 }
 // returns true when K1b and K1c ran as one launch
 static bool launch_eval(mpc_handle *h, const Workspace &w, hipStream_t s, const int *lists, const int *counts,
                         int nG, int nC, hipEvent_t eva = nullptr, hipEvent_t evb = nullptr, int slot_bound = -1,
-                        int *lists_next = nullptr, int *counts_next = nullptr)
+                        int *desc = nullptr)
 {
-    if (h->dc.model == PAC) return launch_eval_t<PAC>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound, lists_next, counts_next);
-    return launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound, lists_next, counts_next);
+    if (h->dc.model == PAC) return launch_eval_t<PAC>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound, desc);
+    return launch_eval_t<KIN>(h, w, s, lists, counts, nG, nC, eva, evb, slot_bound, desc);
 }
 
 // Every entry point that touches the handle's tables, workspace or streams goes through here.  While an
@@ -697,26 +696,37 @@ static hipEvent_t get_event(mpc_handle *h, size_t i)
 }
 
 template <int NE, int MC>
-static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next)
+static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next,
+                          int slot_bound, int par)
 {
-    const size_t lds = MC < 0 ? (size_t)STEP_WAVES * 2 * h->dc.M * h->dc.n * sizeof(double) : 0;
+    size_t lds = MC < 0 ? (size_t)STEP_WAVES * 2 * h->dc.M * h->dc.n * sizeof(double) : 0;
+    // thread-per-agent blocks for the agents that wait in PH_W_LS_G (chain_block): one per 64 gradient slots the
+    // finished round can have held (the same bound that sizes the K1 grids)
+    int nchain = 0;
+    if (NE == 1 && h->dc.chain) {
+        nchain = w.Bp / 64;
+        if (slot_bound >= 0) nchain = std::min(nchain, (slot_bound + 126) / 64 + 1);
+        lds = std::max(lds, sizeof(double) * 2 * 64 * (size_t)(h->dc.n + 1) + sizeof(int) * 128);
+    }
     // agents per workgroup: 16 per wave fills the chip from ~50 k agents; smaller batches trade
     // throughput for latency (a wave walks its agents serially)
     const int apb_env = h->apb_env;
     const int apb = apb_env == 64 || apb_env == 32 || apb_env == 16 || apb_env == 8 || apb_env == 4 ? apb_env
                   : w.B >= 16384 ? 64 : w.B >= 6144 ? 16 : 4; // measured: B = 1 Ki, 4 Ki -> 4; 8 Ki -> 16; 21 Ki -> 64
-    hipLaunchKernelGGL((step_kernel<NE, MC>), dim3((unsigned)((w.B + apb - 1) / apb)), dim3(64 * STEP_WAVES), lds, s,
-                       h->dc, w, lists, counts, counts_next, apb);
+    const int nstep = (w.B + apb - 1) / apb;
+    hipLaunchKernelGGL((step_kernel<NE, MC>), dim3((unsigned)(nstep + nchain)), dim3(64 * STEP_WAVES), lds, s,
+                       h->dc, w, lists, counts, counts_next, apb, nstep, par);
 }
-static void launch_step(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next)
+static void launch_step(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next,
+                        int slot_bound, int par)
 {
     const DevCfg &c = h->dc;
     if (c.n <= 64) { // one element per lane; history rows cached in registers up to M = 20
         // history of one agent in LDS (12.5 KiB per wave at M n = 800: three workgroups per CU)
-        if (!h->step_regs && c.M * c.n <= 800) launch_step_t<1, -1>(h, w, s, lists, counts, counts_next);
-        else if (c.M <= 20) launch_step_t<1, 20>(h, w, s, lists, counts, counts_next);
-        else launch_step_t<1, 0>(h, w, s, lists, counts, counts_next);
-    } else launch_step_t<2, 0>(h, w, s, lists, counts, counts_next);
+        if (!h->step_regs && c.M * c.n <= 800) launch_step_t<1, -1>(h, w, s, lists, counts, counts_next, slot_bound, par);
+        else if (c.M <= 20) launch_step_t<1, 20>(h, w, s, lists, counts, counts_next, slot_bound, par);
+        else launch_step_t<1, 0>(h, w, s, lists, counts, counts_next, slot_bound, par);
+    } else launch_step_t<2, 0>(h, w, s, lists, counts, counts_next, slot_bound, par);
 }
 
 // The persistent wave-per-agent kernel for the agents of view `v` that are still running (`listed`:
@@ -906,11 +916,11 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
                 nev += 5;
             }
             if (ev[0]) (void)hipEventRecord(ev[0], gs[g]);
-            launch_step(h, v, gs[g], lists, counts, counts_next);
+            launch_step(h, v, gs[g], lists, counts, counts_next, r.slot_bound, cur);
             if (ev[1]) (void)hipEventRecord(ev[1], gs[g]);
-            // (the NEXT round's lists: K1c queues the follow-up of a chained gradient request there itself)
-            int *lists_next = v.lists + (size_t)(cur ^ 1) * 2 * v.Ls;
-            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], r.slot_bound, lists_next, counts_next);
+            // (counts[2] of the round's buffer: K1c leaves the number of gradient slots there for the next step
+            // kernel's thread-per-agent blocks)
+            const bool fused = launch_eval(h, v, gs[g], lists, counts, 0, 0, ev[2], ev[3], r.slot_bound, counts + 2);
             if (ev[4]) (void)hipEventRecord(ev[4], gs[g]);
             r.round++;
             rounds_done[g]++;

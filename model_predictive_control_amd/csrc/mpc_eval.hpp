@@ -476,124 +476,10 @@ __device__ __forceinline__ void stage_sens_record(const DevCfg &c, const double 
     }
 }
 
-// ---------------------------------------------------------------- PH_W_LS_G by one THREAD (CHAIN_BIT)
-// The wave-per-agent state machine sums a vector (element j on lane j) as a balanced tree: pairs, quads,
-// halves of eight and rows of sixteen lanes in lane order (row_sum16: every exchange adds commuting operands),
-// then the rows as (r0 + r1) + (r2 + r3) (cross_rows; rows that hold no element are left out, which is adding
-// an exact zero).  A thread that meets the elements two at a time -- stage k = elements 2k, 2k + 1 -- in
-// DESCENDING stage order, as K1c's adjoint recursion produces them, forms the same tree with three holders:
-// same operands at every node, same bits.  Elements beyond n are the zeros the wave adds.
-struct TreeSum {
-    double h1 = 0.0, h2 = 0.0, h3 = 0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-    __device__ __forceinline__ void add(int k, double e0, double e1)          // k wave-uniform
-    {
-#pragma clang fp contract(off)
-        const double t = e0 + e1;                         // lanes 2k, 2k + 1
-        if (k & 1) { h1 = t; return; }
-        const double q = t + h1;                          // stages k, k + 1: a quad of lanes
-        h1 = 0.0;
-        if (k & 2) { h2 = q; return; }
-        const double hf = q + h2;                         // stages k .. k + 3: half a row
-        h2 = 0.0;
-        if (k & 4) { h3 = hf; return; }
-        const double row = hf + h3;                       // stages k .. k + 7: a row of sixteen lanes
-        h3 = 0.0;
-        const int ri = k >> 3;
-        if (ri == 0) r0 = row; else if (ri == 1) r1 = row; else if (ri == 2) r2 = row; else r3 = row;
-    }
-    __device__ __forceinline__ double total(int n) const  // cross_rows<NROWS(n)>
-    {
-#pragma clang fp contract(off)
-        return n <= 32 ? r0 + r1 : n <= 48 ? (r0 + r1) + r2 : (r0 + r1) + (r2 + r3);
-    }
-};
-
-// first lane of the wave among those that call it with on = true does one atomic for all of them; returns the
-// caller's position (callers with on = false: undefined).  May be called inside divergent code.
-__device__ __forceinline__ int wave_append(int *counter, bool on)
-{
-    const unsigned long long bal = __ballot(on);
-    if (bal == 0ull) return 0;
-    const int lane = threadIdx.x & 63;
-    const int leader = (int)__builtin_ctzll(bal);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, (int)__popcll(bal));
-    base = __shfl(base, leader);
-    return base + (int)__popcll(bal & ((1ull << lane) - 1ull));
-}
-
-// What K1c does for a gradient request that carries CHAIN_BIT, per stage inside its adjoint recursion
-// (`stage`) and after it (`finish`): PH_W_LS_G of advance_agent for NE = 1 -- psi+ = psi (or psi(xhat) on the
-// safe step), prox step at the trial point -> xe row, ||p||^2 and grad'p, the speculative Hessian-vector point
-// -> xe2 row -- then the cost request at xhat+ (and the speculative gradient request) straight onto the NEXT
-// round's lists, and the record left as the step kernel would leave it, with PH_INFLIGHT in the phase word.
-// The trial point itself comes from the slot-indexed useq scratch (coalesced), the finite-difference step
-// depends on the point alone and is formed before the recursion starts.
-struct ChainLSG {
-    bool on = false;
-    double gm = 0.0, h = 0.0;
-    const double *useq = nullptr;     // + uslot
-    size_t St = 0;
-    double *xe = nullptr, *xe2 = nullptr;
-    TreeSum spp, sgp;
-    int cnt = 0;
-
-    __device__ __forceinline__ void begin(const DevCfg &c, const Workspace &w, int a, int uslot)
-    {
-#pragma clang fp contract(off)
-        on = true;
-        gm = w.rec[(size_t)a * REC + R_GAMMAN];
-        useq = w.useq + uslot; St = (size_t)w.St;
-        xe = w.xe + (size_t)a * c.n; xe2 = w.xe2 + (size_t)a * c.n;
-        TreeSum sxx;
-        if (!(c.dbg & 8))
-        for (int k = c.N - 1; k >= 0; k--) {
-            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
-            sxx.add(k, 0.0 + x0 * x0, 0.0 + x1 * x1);
-        }
-        h = fd_step(sxx.total(c.n));
-    }
-    __device__ __forceinline__ void stage(const DevCfg &c, int k, double g0, double g1)
-    {
-#pragma clang fp contract(off)
-        const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
-        const double p0 = prox_p(c, 0, x0, g0, gm), p1 = prox_p(c, 1, x1, g1, gm);
-        if (!(c.dbg & 4)) { xe[2 * k] = x0 + p0; xe[2 * k + 1] = x1 + p1; }
-        spp.add(k, fma(p0, p0, 0.0), fma(p1, p1, 0.0));
-        sgp.add(k, fma(g0, p0, 0.0), fma(g1, p1, 0.0));
-        if (!c.no_spec) {
-            const bool in0 = in_J(c, 0, x0, g0, gm), in1 = in_J(c, 1, x1, g1, gm);
-            cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
-            const double q0 = in0 ? 0.0 : p0, q1 = in1 ? 0.0 : p1;
-            if (!(c.dbg & 2)) { xe2[2 * k] = x0 + h * q0; xe2[2 * k + 1] = x1 + h * q1; }
-        }
-    }
-    __device__ __forceinline__ void finish(const DevCfg &c, const Workspace &w, int a, double psi,
-                                           int *__restrict__ lists_next, int *__restrict__ counts_next)
-    {
-        double *r = w.rec + (size_t)a * REC;
-        const bool spec = !c.no_spec && cnt > 0 && cnt < c.n;
-        r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : psi;
-        r[R_PPN] = spp.total(c.n); r[R_GPN] = sgp.total(c.n);
-        r[R_SPEC] = spec ? 1.0 : 0.0;
-        if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
-        r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
-        r[R_PHASE] = (double)(PH_W_LS_C + PH_INFLIGHT);
-        const int pc = wave_append(&counts_next[1], true);
-        lists_next[(size_t)w.Ls + pc] = a | CHAIN_BIT;
-        const int pg = wave_append(&counts_next[0], spec);
-        if (spec) lists_next[pg] = a | CH2_BIT;
-    }
-};
-
 // K1c for one request: psi = sum of stage costs (stage order, as main.py:36-40) and the adjoint
 // recursion over the stage records; `get(k, f)` reads field f of stage k.
-// raw / uslot / lists_next / counts_next: the request's list entry and slot and the NEXT round's lists, for the
-// chained step (CHAIN_BIT; raw = 0 and null lists where there is none: standalone evaluation, persistent kernel).
 template <int MODEL, class Get>
-__device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g, Get get,
-                                            int raw = 0, int uslot = 0, int *__restrict__ lists_next = nullptr,
-                                            int *__restrict__ counts_next = nullptr)
+__device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g, Get get)
 {
     constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE;
     const int N = c.N, n = c.n;
@@ -601,14 +487,7 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
     for (int k = 0; k < N; k++) psi += get(k, JS);
     if (w.psi_direct) w.psi_direct[a] = psi;
     else if (!ch2) w.rec[(size_t)a * REC + R_PSIE] = psi;
-    const bool chained = (raw & CHAIN_BIT) != 0 && lists_next != nullptr;
-    if (!is_g) {
-        // a cost request that K1c queued itself: the agent takes part in the next step kernel again
-        if (chained) w.rec[(size_t)a * REC + R_PHASE] = (double)PH_W_LS_C;
-        return;
-    }
-    ChainLSG ch;
-    if (chained) ch.begin(c, w, a, uslot);
+    if (!is_g) return;
     double lam[NX];
 #pragma unroll
     for (int i = 0; i < NX; i++) lam[i] = 0.0;
@@ -635,10 +514,9 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
         }
 #pragma unroll
         for (int jj = 0; jj < NZ; jj++) lam[2 + jj] = lz[jj];
-        if (!(c.dbg & 1)) { grow[2 * k] = gu[0]; grow[2 * k + 1] = gu[1]; }
-        if (ch.on) ch.stage(c, k, gu[0], gu[1]);
+        grow[2 * k] = gu[0];
+        grow[2 * k + 1] = gu[1];
     }
-    if (ch.on) ch.finish(c, w, a, psi, lists_next, counts_next);
 }
 
 // K1b.  With `w.arrive` set it also does K1c for a block of 64 slots, in the stage-block that finishes
@@ -731,11 +609,13 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
 template <int MODEL>
 __global__ void __launch_bounds__(64)
 adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
-               int *__restrict__ lists_next, int *__restrict__ counts_next)
+               int *__restrict__ desc)
 {
     constexpr int JS = JacRec<MODEL>::SIZE;
     const SlotMap sm(counts, nG_imm, nC_imm);
     const int sb = blockIdx.x;
+    // for the next step kernel's thread-per-agent blocks (chain_block): the gradient slots of this round
+    if (desc && sb == 0 && threadIdx.x == 0) *desc = sm.gpad;
     if (sb >= sm.nblk) return;
     const bool is_g = sb < sm.nblk_g;
     const int uslot = sb * 64 + threadIdx.x;
@@ -745,7 +625,7 @@ adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts
     const double *const jac = w.jac + uslot, *const sl = w.stage_L + uslot;
     adjoint_rec<MODEL>(c, w, raw & AGENT_MASK, (raw & CH2_BIT) != 0, is_g, [=](int k, int f) {
         return f == JS ? sl[(size_t)k * St] : jac[((size_t)k * JS + f) * St];
-    }, raw, uslot, lists_next, counts_next);
+    });
 }
 
 // K1b + K1c in one launch: a workgroup takes SPB = BLK / N consecutive slots; thread (k, j) does stage
@@ -759,13 +639,14 @@ template <int MODEL> struct FusedBlk { static constexpr int BLK = MODEL == PAC ?
 template <int MODEL, bool SHARED_CL>
 __global__ void __launch_bounds__(FusedBlk<MODEL>::BLK, 2)
 stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
-                     int *__restrict__ lists_next, int *__restrict__ counts_next)
+                     int *__restrict__ desc)
 {
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE, BLK = FusedBlk<MODEL>::BLK;
     extern __shared__ double s_rec[];                    // [JS + 1][N][SPB]; row JS = stage cost
     const SlotMap sm(counts, nG_imm, nC_imm);
     const int N = c.N, SPB = BLK / N;
     const int slot0 = blockIdx.x * SPB, nslots = sm.nblk * 64;
+    if (desc && blockIdx.x == 0 && threadIdx.x == 0) *desc = sm.gpad;   // see adjoint_kernel
     if (slot0 >= nslots) return;
     const size_t St = (size_t)w.St;
     const int NS = N * SPB;
@@ -800,7 +681,7 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
     if (raw < 0) return;
     const double *const rj = s_rec + j;
     adjoint_rec<MODEL>(c, w, raw & AGENT_MASK, (raw & CH2_BIT) != 0, uslot < sm.gpad,
-                       [=](int k, int f) { return rj[(size_t)f * NS + k * SPB]; }, raw, uslot, lists_next, counts_next);
+                       [=](int k, int f) { return rj[(size_t)f * NS + k * SPB]; });
 }
 
 } // namespace mpc

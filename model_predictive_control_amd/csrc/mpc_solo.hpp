@@ -162,21 +162,6 @@ solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int
         const int a = list ? list[i] : i;
         for (long long trip = 0; trip < max_trips; trip++) {
             const AgentIn<NE> in = load_agent<NE>(c, w, a, lane);
-            const int ph = (int)rdlane(in.rv, R_PHASE);
-            if (ph >= PH_INFLIGHT) {                                        // uniform
-                // The round path had this agent's next evaluation queued for a round that never ran (K1c's
-                // chained step, CHAIN_BIT: the cost at the prox point of its line-search trial, and maybe the
-                // speculative gradient beside it) when its group left the rounds: run it now.  A speculative
-                // gradient that this kernel does not evaluate (wave-per-request rollout) is withdrawn -- the
-                // next iteration then asks for that gradient the ordinary way: same bits, same count.
-                const bool sp = (int)rdlane(in.rv, R_SPEC) != 0;
-                solo_eval<MODEL>(c, w, a, lane, REQ_COST | (sp && spec ? REQ_SPEC : 0), traj, rec);
-                if (lane == 0) {
-                    w.rec[(size_t)a * REC + R_PHASE] = (double)(ph - PH_INFLIGHT);
-                    if (sp && !spec) w.rec[(size_t)a * REC + R_SPEC] = 0.0;
-                }
-                continue;
-            }
             const int req = advance_agent<NE, MC>(c, w, a, lane, in, hist, false, /*allow_spec=*/spec);
             if ((req & (REQ_GRAD | REQ_COST)) == 0) break;              // uniform: the agent is done
             solo_eval<MODEL>(c, w, a, lane, req, traj, rec);

@@ -38,17 +38,21 @@ enum { ST_UNKNOWN = 0, ST_CONVERGED = 1, ST_MAXTIME = 2, ST_MAXITER = 3, ST_NOTF
 enum { REQ_NONE = 0, REQ_GRAD = 1, REQ_COST = 2, REQ_SPEC = 4, // bit set; SPEC = gradient on channel 2
        REQ_CHAIN = 8 };  // with REQ_GRAD: the gradient at a line-search trial point, whose follow-up K1c may run itself
 // a work-list entry is the agent id, plus CH2_BIT when the evaluation runs on the speculative
-// channel (input row xe2, gradient row ge2, nothing else written), plus CHAIN_BIT:
-//   on the gradient list: the gradient at a line-search trial point (PH_LS_TRIAL -> PH_W_LS_G).  What the agent
-//     does with it is fixed and elementwise -- prox step at the trial point, request the cost there, speculate
-//     (PH_W_LS_G) -- so the evaluation's last kernel does it, one THREAD per agent (chain_ls_g in mpc_eval.hpp),
-//     and queues the follow-up requests on the next round's lists itself: the agent skips the step kernel
-//     for a round (its phase word carries PH_INFLIGHT meanwhile), a third of all agent-steps;
-//   on the cost list: such a queued cost request -- K1c clears PH_INFLIGHT when it has served it.
+// channel (input row xe2, gradient row ge2, nothing else written), plus CHAIN_BIT on the gradient list when
+// it is the gradient at a line-search trial point (PH_LS_TRIAL -> PH_W_LS_G).  What the agent does with that
+// gradient is fixed and elementwise -- prox step at the trial point, request the cost there, speculate
+// (PH_W_LS_G) -- and is done for it by one THREAD instead of one wavefront: the next step-kernel launch carries
+// extra workgroups (chain_block) that walk the gradient slots of the finished round, 64 per workgroup, and do
+// PH_W_LS_G for the entries with this bit -- a third of all agent-steps at a fifth of the instructions.
 constexpr int CH2_BIT = 1 << 30;
 constexpr int CHAIN_BIT = 1 << 29;
 constexpr int AGENT_MASK = CHAIN_BIT - 1;
-constexpr int PH_INFLIGHT = 64;   // added to the phase word of an agent whose next evaluation is already queued
+// A chain_block runs beside the wave-per-agent blocks of the same launch, which must not pick up the agent it has
+// just moved to PH_W_LS_C (its cost evaluation has not run yet): it writes the phase with a tag of the launch's
+// parity, PH_W_LS_C + 64 (1 + round % 2); the blocks of a launch leave agents with their own launch's tag alone
+// and take those with the other one -- written a round ago, the evaluation done -- and the tag is dropped.
+constexpr int PH_MASK = 63;
+__device__ __forceinline__ int chain_tag(int par) { return 64 * (1 + par); }
 
 struct Workspace {
     const double *x0;                              // [B][nx]   caller's buffer
@@ -566,6 +570,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     RecI memo_evals{rv, lane, R_MEMO_EVALS};
     RecD memo_mineps{rv, lane, R_MEMO_MINEPS};
     RecD memo_eps{rv, lane, R_MEMO_EPS};
+    if (phase > PH_MASK) phase = (int)phase & PH_MASK;   // (a chain_block's launch tag: see chain_tag)
     double t_pp, t_gp;
     int lb_rows = 0, n_grad = 0;
     int req = REQ_NONE;
@@ -1025,6 +1030,151 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     return req;
 }
 
+// ---------------------------------------------------------------- PH_W_LS_G by one THREAD (CHAIN_BIT)
+// The wave-per-agent state machine sums a vector (element j on lane j) as a balanced tree: pairs, quads,
+// halves of eight and rows of sixteen lanes in lane order (row_sum16: every exchange adds commuting operands),
+// then the rows as (r0 + r1) + (r2 + r3) (cross_rows; rows that hold no element are left out, which is adding
+// an exact zero).  A thread that meets the elements two at a time -- stage k = elements 2k, 2k + 1 -- in
+// DESCENDING stage order forms the same tree with three holders:
+// same operands at every node, same bits.  Elements beyond n are the zeros the wave adds.
+struct TreeSum {
+    double h1 = 0.0, h2 = 0.0, h3 = 0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    __device__ __forceinline__ void add(int k, double e0, double e1)          // k wave-uniform
+    {
+#pragma clang fp contract(off)
+        const double t = e0 + e1;                         // lanes 2k, 2k + 1
+        if (k & 1) { h1 = t; return; }
+        const double q = t + h1;                          // stages k, k + 1: a quad of lanes
+        h1 = 0.0;
+        if (k & 2) { h2 = q; return; }
+        const double hf = q + h2;                         // stages k .. k + 3: half a row
+        h2 = 0.0;
+        if (k & 4) { h3 = hf; return; }
+        const double row = hf + h3;                       // stages k .. k + 7: a row of sixteen lanes
+        h3 = 0.0;
+        const int ri = k >> 3;
+        if (ri == 0) r0 = row; else if (ri == 1) r1 = row; else if (ri == 2) r2 = row; else r3 = row;
+    }
+    __device__ __forceinline__ double total(int n) const  // cross_rows<NROWS(n)>
+    {
+#pragma clang fp contract(off)
+        return n <= 32 ? r0 + r1 : n <= 48 ? (r0 + r1) + r2 : (r0 + r1) + (r2 + r3);
+    }
+};
+
+// first lane of the wave among those that call it with on = true does one atomic for all of them; returns the
+// caller's position (callers with on = false: undefined).  May be called inside divergent code.
+__device__ __forceinline__ int wave_append(int *counter, bool on)
+{
+    const unsigned long long bal = __ballot(on);
+    if (bal == 0ull) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = (int)__builtin_ctzll(bal);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, (int)__popcll(bal));
+    base = __shfl(base, leader);
+    return base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+}
+
+// A workgroup of the step-kernel launch (blocks nstep ..) that serves 64 gradient slots of the FINISHED round:
+// for every slot whose entry carries CHAIN_BIT it does what PH_W_LS_G of advance_agent does (NE = 1) -- psi+ =
+// psi (or psi(xhat) on the safe step), prox step at the trial point -> xe row, ||p||^2 and grad'p, the
+// speculative Hessian-vector point -> xe2 row, the cost request (and the speculative gradient request) onto
+// this round's lists, the record left as advance_agent leaves it -- with ONE THREAD per agent.  The gradient rows
+// come in through an LDS tile (coalesced, all four waves), the trial point from the slot-indexed useq scratch of
+// the finished round (coalesced; K1a of this round has not run yet), the results leave through the tiles again;
+// wave 0 does the arithmetic, 40 elements per lane, with the sums formed as the wave reductions form them.
+// ~2 000 wave-instructions per 64 slots, against ~350 per AGENT for the wave-per-agent step.
+__device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w, int cb, int gpad, int par,
+                                            int *__restrict__ lists_out, int *__restrict__ counts_out, double *lds)
+{
+#pragma clang fp contract(off)   // fixed roundings: the same bits as the wave-per-agent PH_W_LS_G
+    const int n = c.n, N = c.N, ld = n + 1, t = threadIdx.x;
+    const int slot0 = cb * 64;
+    if (slot0 >= gpad) return;                           // uniform: no gradient slots here
+    double *tA = lds, *tB = lds + 64 * ld;
+    int *s_agent = (int *)(tB + 64 * ld);                // [0, 64): agent of the slot or -1; [64, 128): speculation issued
+    if (t < 64) {
+        const int uslot = slot0 + t;
+        const int raw = uslot < gpad ? w.agent_of[uslot] : -1;
+        const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0;
+        s_agent[t] = on ? (raw & AGENT_MASK) : -1;
+        s_agent[64 + t] = 0;
+    }
+    __syncthreads();
+    const int total = 64 * n;
+    for (int base = 0; base < total; base += 256 * 4) {  // gradient rows -> tile A, four loads in flight per thread
+        double v[4];
+        int off[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = base + u * 256 + t;
+            const int r = idx / n, j = idx - r * n;
+            const int ar = idx < total ? s_agent[r] : -1;
+            off[u] = ar >= 0 ? r * ld + j : -1;
+            v[u] = ar >= 0 ? w.ge[(size_t)ar * n + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (off[u] >= 0) tA[off[u]] = v[u];
+    }
+    __syncthreads();
+    if (t < 64 && s_agent[t] >= 0) {
+        const int a = s_agent[t];
+        double *r = w.rec + (size_t)a * REC;
+        const double gm = r[R_GAMMAN];
+        const double *useq = w.useq + slot0 + t;
+        const size_t St = (size_t)w.St;
+        TreeSum sxx;                                     // speculate(): xx = sum of squares of the trial point
+        for (int k = N - 1; k >= 0; k--) {
+            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
+            sxx.add(k, 0.0 + x0 * x0, 0.0 + x1 * x1);
+        }
+        const double h = fd_step(sxx.total(n));
+        double *ga = tA + t * ld, *gb = tB + t * ld;
+        TreeSum spp, sgp;
+        int cnt = 0;
+        for (int k = N - 1; k >= 0; k--) {
+            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
+            const double g0 = ga[2 * k], g1 = ga[2 * k + 1];
+            const double p0 = prox_p(c, 0, x0, g0, gm), p1 = prox_p(c, 1, x1, g1, gm);   // prox_to_xe
+            ga[2 * k] = x0 + p0; ga[2 * k + 1] = x1 + p1;
+            spp.add(k, fma(p0, p0, 0.0), fma(p1, p1, 0.0));
+            sgp.add(k, fma(g0, p0, 0.0), fma(g1, p1, 0.0));
+            if (!c.no_spec) {                                                          // speculate()
+                const bool in0 = in_J(c, 0, x0, g0, gm), in1 = in_J(c, 1, x1, g1, gm);
+                cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+                const double q0 = in0 ? 0.0 : p0, q1 = in1 ? 0.0 : p1;
+                gb[2 * k] = x0 + h * q0; gb[2 * k + 1] = x1 + h * q1;
+            }
+        }
+        const bool spec = !c.no_spec && cnt > 0 && cnt < n;
+        r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : r[R_PSIE];
+        r[R_PPN] = spp.total(n); r[R_GPN] = sgp.total(n);
+        r[R_SPEC] = spec ? 1.0 : 0.0;
+        if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
+        r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
+        r[R_PHASE] = (double)(PH_W_LS_C + chain_tag(par));
+        s_agent[64 + t] = spec ? 1 : 0;
+        const int pc = wave_append(&counts_out[1], true);
+        lists_out[(size_t)w.Ls + pc] = a;
+        const int pg = wave_append(&counts_out[0], spec);
+        if (spec) lists_out[pg] = a | CH2_BIT;
+    }
+    __syncthreads();
+    for (int base = 0; base < total; base += 256 * 4) {  // tiles -> xe rows (and xe2 rows where speculation was issued)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = base + u * 256 + t;
+            const int r = idx / n, j = idx - r * n;
+            const int ar = idx < total ? s_agent[r] : -1;
+            if (ar >= 0) {
+                w.xe[(size_t)ar * n + j] = tA[r * ld + j];
+                if (s_agent[64 + r]) w.xe2[(size_t)ar * n + j] = tB[r * ld + j];
+            }
+        }
+    }
+}
+
 // One wave per agent at a time; a 256-thread workgroup owns 64 consecutive agents (each of its
 // 4 waves walks 16 of them), collects their requests in LDS and appends them to the round's
 // gradient / cost work lists with one atomic per list, in agent order.
@@ -1033,8 +1183,16 @@ constexpr int STEP_WAVES = 4;
 template <int NE, int MC>
 __global__ void __launch_bounds__(64 * STEP_WAVES, 2)
 step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
-            int *__restrict__ counts_out, int *__restrict__ counts_next, int apb)
+            int *__restrict__ counts_out, int *__restrict__ counts_next, int apb, int nstep, int par)
 {
+    // blocks [0, nstep): the wave-per-agent state machine; blocks beyond (c.chain): PH_W_LS_G by one thread per
+    // agent for the gradient slots of the round just finished, whose count K1c left in counts_next[2] (the buffer
+    // of that round: this kernel zeroes its two list counters for the round after this one, not that word)
+    if ((int)blockIdx.x >= nstep) {
+        extern __shared__ double s_chain[];
+        if (NE == 1) chain_block(c, w, (int)blockIdx.x - nstep, counts_next[2], par, lists_out, counts_out, s_chain);
+        return;
+    }
     // apb = agents per workgroup (64, 16 or 4): a wave walks its agents one after the other, so a small
     // batch is spread over more workgroups (one agent per wave at apb = 4) -- latency, not throughput
     __shared__ int s_req[64];
@@ -1048,8 +1206,8 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     // find out that an agent is finished.
     const int base = blockIdx.x * apb;
     const double phw = lane < apb && base + lane < w.B ? w.rec[(size_t)(base + lane) * REC + R_PHASE] : 0.0;
-    // (PH_DONE == 0; an agent whose next evaluation K1c has already queued -- PH_INFLIGHT -- has nothing to do here)
-    const bool runnable = phw != 0.0 && phw < (double)PH_INFLIGHT;
+    // (PH_DONE == 0; with c.chain an agent that waits in PH_W_LS_G is served by a chain_block of this launch)
+    const bool runnable = phw != 0.0 && !(c.chain && (phw == (double)PH_W_LS_G || phw == (double)(PH_W_LS_C + chain_tag(par))));
     const unsigned long long act = __ballot(runnable);
     const int rank = __popcll(act & ((1ull << lane) - 1ull));
     const int nact = __popcll(act);
@@ -1069,7 +1227,7 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     AgentIn<NE> nxt;
     int loc = claim();
     // (MPC_ALL_ROWS: the six-row fetch of rounds 1 - 2, for the A/B measurement and the bit-identity test)
-    const auto phase_of = [&](int l) { return c.all_rows ? -1 : (int)rdlane(phw, l); };
+    const auto phase_of = [&](int l) { return c.all_rows ? -1 : ((int)rdlane(phw, l) & PH_MASK); };
     if (loc >= 0) nxt = load_agent<NE>(c, w, base + loc, lane, phase_of(loc));
     while (loc >= 0) {
         const int a = base + loc;
@@ -1083,7 +1241,7 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
             // LDS-DMA of its history now.  Issued BEHIND the next agent's row loads: the wait for the
             // history drains the wave's vector-memory queue in order, so nothing younger than what it
             // needs should be in it.
-            const int ph = (int)rdlane(cur.rv, R_PHASE);
+            const int ph = (int)rdlane(cur.rv, R_PHASE) & PH_MASK;
             const int hi = (int)rdlane(cur.rv, R_LIDX), hf = (int)rdlane(cur.rv, R_LFULL);
             const int hl = hi | hf;
             const int sp = (int)rdlane(cur.rv, R_SPEC);
