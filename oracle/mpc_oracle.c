@@ -727,8 +727,9 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
         }
         double phin, psin, psixhn, gpn, ppn, Ln, gamman, ls_cond;
         g_lsc[1] += 1; P->in_ls = 1;
+        int it_trials = 0; double qub_before = g_lsc[2];
         do {
-            g_lsc[0] += 1;
+            g_lsc[0] += 1; it_trials++;
             Ln = Lk; gamman = gamma;
             if (tau / 2.0 < c->tau_min) {
                 g_lsc[6] += 1;
@@ -752,6 +753,10 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
              * alpaqa's literal `ls_cond > margin` would accept it because NaN compares false */
         } while (!(ls_cond <= margin) && tau >= c->tau_min);
         P->in_ls = 0;
+        /* dependent evaluation trips of this line search if up to four trial points are evaluated side by side:
+         * one trip for the gradients of up to four trials, one per two trials for their costs (+ speculative
+         * gradients), one per descent-lemma doubling */
+        g_lsc[7] += (it_trials + 3) / 4 + (it_trials + 1) / 2 + (g_lsc[2] - qub_before);
 
         if (gamma != gamman) lbfgs_reset(lb);
         lbfgs_update(lb, xk, xn, gk, gn);
