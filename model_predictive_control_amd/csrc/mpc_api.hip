@@ -44,6 +44,7 @@ struct mpc_handle {
     int *arrive_buf = nullptr;  // arrival counters, one per block of 64 slots
     bool quad_rollout = true;   // K1a by two (kinematic) / four (Pacejka) lanes per request (MPC_NO_QUAD: one thread)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
+    int lds_pairs = 0;          // MPC_LDS_PAIRS: history pairs the step kernel's LDS copy holds (0 = chosen by launch_step_t)
     int num_cus = 256;
     // block bounding boxes of the centerline table last handed to mpc_centerline_blocks
     double *cl_boxes = nullptr;
@@ -256,6 +257,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (device < 0 || device >= ndev) return fail(MPC_E_ARG, "mpc_create: no such device");
     mpc_handle *h = new mpc_handle();
     h->step_regs = getenv("MPC_STEP_REGS") != nullptr;
+    if (getenv("MPC_LDS_PAIRS")) h->lds_pairs = atoi(getenv("MPC_LDS_PAIRS"));
     h->quad_rollout = getenv("MPC_NO_QUAD") == nullptr;
     h->arrive_adjoint = getenv("MPC_ARRIVE") != nullptr;
     if (getenv("MPC_WIDE_MAX")) h->wide_max = atoi(getenv("MPC_WIDE_MAX"));
@@ -699,14 +701,24 @@ template <int NE, int MC>
 static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next,
                           int slot_bound, int par)
 {
-    size_t lds = MC < 0 ? (size_t)STEP_WAVES * 2 * h->dc.M * h->dc.n * sizeof(double) : 0;
+    // LDS copy of an agent's L-BFGS history (MC < 0): the ring slots 0 .. P - 1.  The unconstrained variant runs four
+    // waves per SIMD (128 registers), so P is what lets four workgroups share a CU's 160 KB -- 15 pairs at n = 40,
+    // where an application reads 5.4 on average; a longer history reads its remaining slots from global memory
+    int P = h->dc.M;
+    if (MC < 0 && NE == 1 && h->dc.m == 0) {
+        const size_t per_pair = (size_t)STEP_WAVES * 2 * h->dc.n * sizeof(double);
+        const int fit = (int)((160 * 1024 / 4 - 512) / per_pair);
+        P = std::max(1, std::min(P, fit));
+    }
+    if (h->lds_pairs > 0) P = std::max(1, std::min(h->dc.M, h->lds_pairs));   // MPC_LDS_PAIRS: experiments, tests
+    size_t lds = MC < 0 ? (size_t)STEP_WAVES * 2 * P * h->dc.n * sizeof(double) : 0;
     // thread-per-agent blocks for the agents that wait in PH_W_LS_G (chain_block): one per 64 gradient slots the
     // finished round can have held (the same bound that sizes the K1 grids)
     int nchain = 0;
     if (NE == 1 && h->dc.chain) {
         nchain = w.Bp / 64;
         if (slot_bound >= 0) nchain = std::min(nchain, (slot_bound + 126) / 64 + 1);
-        lds = std::max(lds, sizeof(double) * 2 * 64 * (size_t)(h->dc.n + 1) + sizeof(int) * 128);
+        lds = std::max(lds, sizeof(double) * 2 * CHAIN_SLOTS * (size_t)(h->dc.n + 1) + sizeof(int) * 2 * CHAIN_SLOTS);
     }
     // agents per workgroup: 16 per wave fills the chip from ~50 k agents; smaller batches trade
     // throughput for latency (a wave walks its agents serially)
@@ -714,8 +726,12 @@ static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int 
     const int apb = apb_env == 64 || apb_env == 32 || apb_env == 16 || apb_env == 8 || apb_env == 4 ? apb_env
                   : w.B >= 16384 ? 64 : w.B >= 6144 ? 16 : 4; // measured: B = 1 Ki, 4 Ki -> 4; 8 Ki -> 16; 21 Ki -> 64
     const int nstep = (w.B + apb - 1) / apb;
-    hipLaunchKernelGGL((step_kernel<NE, MC>), dim3((unsigned)(nstep + nchain)), dim3(64 * STEP_WAVES), lds, s,
-                       h->dc, w, lists, counts, counts_next, apb, nstep, par);
+    if (h->dc.m == 0)
+        hipLaunchKernelGGL((step_kernel<NE, MC, false>), dim3((unsigned)(nstep + nchain)), dim3(64 * STEP_WAVES), lds, s,
+                           h->dc, w, lists, counts, counts_next, apb, nstep, par, P);
+    else
+        hipLaunchKernelGGL((step_kernel<NE, MC, true>), dim3((unsigned)(nstep + nchain)), dim3(64 * STEP_WAVES), lds, s,
+                           h->dc, w, lists, counts, counts_next, apb, nstep, par, P);
 }
 static void launch_step(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next,
                         int slot_bound, int par)
@@ -900,7 +916,10 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         gr[0].active = false; nactive = 0;
     }
     int rc_loop = MPC_OK;
-    auto queue_window = [&](int g) {            // `check_every` rounds of group g, then the copy of its counters
+    double host_queue_s = 0.0;                  // host time spent queueing launches (MPC_HOST_TIMING: printed at the end)
+    static const bool host_timing = getenv("MPC_HOST_TIMING") != nullptr;
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    auto queue_window_impl = [&](int g) {       // `check_every` rounds of group g, then the copy of its counters
         GroupRun &r = gr[g];
         const Workspace &v = gv[g];
         int cur = 0;
@@ -935,6 +954,12 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         if (hipMemcpyAsync(h->host_counts + 16 * wb + 2 * g, v.counts + cur * 4, 2 * sizeof(int), hipMemcpyDeviceToHost, gs[g]) != hipSuccess ||
             hipEventRecord(h->pollev[wb][g], gs[g]) != hipSuccess) { rc_loop = MPC_E_HIP; return; }
         r.window++;
+    };
+    auto queue_window = [&](int g) {
+        if (!host_timing) { queue_window_impl(g); return; }
+        const auto t0 = std::chrono::steady_clock::now();
+        queue_window_impl(g);
+        host_queue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
     // what the counters of window `pb` say about group g; returns false when the group is done with rounds
     auto decide = [&](int g, int pb) {
@@ -992,6 +1017,10 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         else
             std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
+    if (host_timing)
+        fprintf(stderr, "[mpc host] round loop %.2f ms, of which queueing launches %.2f ms (%lld launch sets, %d groups)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(),
+                host_queue_s * 1e3, launch_sets, ng);
     if (rc_loop == MPC_E_LIMIT) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
     if (rc_loop != MPC_OK) return fail(rc_loop, "mpc_solve_batch: HIP error in the round loop");
     {

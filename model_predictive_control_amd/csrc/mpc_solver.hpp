@@ -299,9 +299,12 @@ __device__ __forceinline__ void prox_to_xe(const DevCfg &c, double *__restrict__
 
 // The S and Y history blocks of one agent (M n doubles each, contiguous) copied to LDS by the
 // LDS-DMA path: 16 B per lane and instruction, no VGPRs, completion tracked by vmcnt.
+// (Mn = P n: the LDS copy holds the ring slots 0 .. P - 1 of each block, P <= M -- the rest of a long history
+// is read from global memory by the two-loop)
 __device__ __forceinline__ void hist_dma(const double *__restrict__ gS, const double *__restrict__ gY,
                                          double *hist, int Mn, int rows_n, int lane)
 {
+    rows_n = rows_n < Mn ? rows_n : Mn;
     // only the ring slots in use are fetched: the first `rows_n` doubles of each block (a ring that
     // has not wrapped yet holds its pairs in slots 0 .. lidx-1; the history is flushed whenever the
     // step size changes, so on average it is far from full)
@@ -332,7 +335,9 @@ template <int NE, int MC>
 __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__restrict__ Sa,
                                                const double *__restrict__ Ya, int n, int lane,
                                                const bool (&inj)[NE], int lidx, int lfull,
-                                               Row<NE> &q, int &rows_read)
+                                               Row<NE> &q, int &rows_read, int P = 1 << 30,
+                                               const double *__restrict__ Sg = nullptr,
+                                               const double *__restrict__ Yg = nullptr)
 {
 #pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
     const int M = c.M;
@@ -386,7 +391,7 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
     };
     auto load_masked = [&](int t, Row<NE> &s, Row<NE> &y) {
         int i = lidx - 1 - t; if (i < 0) i += M;
-        if (MC < 0) {
+        if (MC < 0 && i < P) {                           // (uniform) the wave's LDS copy holds ring slots 0 .. P - 1
             typedef const __attribute__((address_space(3))) double lds_cd;
             lds_cd *ls = (lds_cd *)Sa + i * n, *ly = (lds_cd *)Ya + i * n;
 #pragma unroll
@@ -394,6 +399,9 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
                 const int j = lane + 64 * e < n ? lane + 64 * e : 0;
                 s.v[e] = ls[j]; y.v[e] = ly[j];
             }
+        } else if (MC < 0) {                             // a slot beyond the copy: from the history in global memory
+            s = ldrow<NE>(Sg + (size_t)i * n, n, lane);
+            y = ldrow<NE>(Yg + (size_t)i * n, n, lane);
         } else {
             s = ldrow<NE>(Sa + (size_t)i * n, n, lane);
             y = ldrow<NE>(Ya + (size_t)i * n, n, lane);
@@ -494,12 +502,16 @@ __device__ __forceinline__ AgentIn<NE> load_agent(const DevCfg &c, const Workspa
     return in;
 }
 
-template <int NE, int MC>
+// HASM = false: the caller knows that the problem has no constraints (m == 0) -- every multiplier / penalty loop
+// and the eight pointers behind them drop out of the code (fewer live scalar registers in the round path's kernel).
+template <int NE, int MC, bool HASM = true>
 __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lane, const AgentIn<NE> &in,
-                             double *hist, bool hist_ready, bool allow_spec = true, bool allow_chain = false)
+                             double *hist, bool hist_ready, bool allow_spec = true, bool allow_chain = false,
+                             int P = 1 << 30)
 {
 #pragma clang fp contract(off)   // fixed roundings: the step kernel and the persistent kernel must agree bit for bit
-    const int n = c.n, m = c.m;
+    const int n = c.n, m = HASM ? c.m : 0;
+    if (P > c.M) P = c.M;                                // ring slots of the history that the LDS copy holds (MC < 0)
     const size_t an = (size_t)a * n, am = (size_t)a * m;
     double *recp = w.rec + (size_t)a * REC;
     // The ~50 per-agent scalars live in LDS for the duration of the step (wave-uniform values would
@@ -833,13 +845,14 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
 #pragma unroll
                 for (int e = 0; e < NE; e++) inj[e] = lane + 64 * e < n && in_J(c, par, x.v[e], g.v[e], gamma);
                 const double *Sa = w.S + (size_t)a * c.M * n, *Ya = w.Y + (size_t)a * c.M * n;
+                const double *const Sg = Sa, *const Yg = Ya;
                 if (MC < 0) {
-                    if (!hist_ready && (lidx | lfull) != 0) hist_dma(Sa, Ya, hist, c.M * n, (lfull ? c.M : (int)lidx) * n, lane);
+                    if (!hist_ready && (lidx | lfull) != 0) hist_dma(Sa, Ya, hist, P * n, (lfull ? c.M : (int)lidx) * n, lane);
                     hist_ready = false;
                     if (!hist_landed) hist_wait();
-                    Sa = hist; Ya = hist + c.M * n;
+                    Sa = hist; Ya = hist + P * n;
                 }
-                const bool ok = lbfgs_two_loop<NE, MC>(c, Sa, Ya, n, lane, inj, lidx, lfull, qv, lb_rows);
+                const bool ok = lbfgs_two_loop<NE, MC>(c, Sa, Ya, n, lane, inj, lidx, lfull, qv, lb_rows, P, Sg, Yg);
                 if (!ok) {
 #pragma unroll
                     for (int e = 0; e < NE; e++) if (inj[e]) qv.v[e] *= gamma;
@@ -928,7 +941,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                     // the prefetched LDS copy of the history gets the new pair too; the wait comes before
                     // this step's first global stores so that it does not have to drain them
                     hist_wait(); hist_landed = true;
-                    if (lane < n) { hist[(int)lidx * n + lane] = s.v[0]; hist[(c.M + (int)lidx) * n + lane] = yv.v[0]; }
+                    if (lane < n && lidx < P) { hist[(int)lidx * n + lane] = s.v[0]; hist[(P + (int)lidx) * n + lane] = yv.v[0]; }
                 }
                 strow<NE>(w.S + ((size_t)a * c.M + lidx) * n, n, lane, s);
                 strow<NE>(w.Y + ((size_t)a * c.M + lidx) * n, n, lane, yv);
@@ -977,7 +990,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             if (backtrack) {
                 if (!first) {
                     Delta = fmax(1.0, Delta * c.Delta_lower);
-                    update_penalty(c, w, am, lane, Delta, first, ne1);
+                    if (HASM) update_penalty(c, w, am, lane, Delta, first, ne1);
                     rho_alm = fmin(0.5, rho_alm * c.rho_increase);
                     eps = fmax(rho_alm * eps_old, c.alm_eps);
                     pen_red += 1;
@@ -1007,7 +1020,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                     const double t = w.Sig_old[am + kk];
                     w.Sig_old[am + kk] = w.Sig[am + kk]; w.Sig[am + kk] = t;
                 }
-                update_penalty(c, w, am, lane, Delta, first, ne1);
+                if (HASM) update_penalty(c, w, am, lane, Delta, first, ne1);
                 eps_old = eps;
                 eps = fmax(rho_alm * eps, c.alm_eps);
                 first = 0;
@@ -1083,93 +1096,101 @@ __device__ __forceinline__ int wave_append(int *counter, bool on)
 // this round's lists, the record left as advance_agent leaves it -- with ONE THREAD per agent.  The gradient rows
 // come in through an LDS tile (coalesced, all four waves), the trial point from the slot-indexed useq scratch of
 // the finished round (coalesced; K1a of this round has not run yet), the results leave through the tiles again;
-// wave 0 does the arithmetic, 40 elements per lane, with the sums formed as the wave reductions form them.
+// in two passes of 32 slots; half a wave does the arithmetic, 40 elements per lane, with the sums formed as the
+// wave reductions form them.
 // ~2 000 wave-instructions per 64 slots, against ~350 per AGENT for the wave-per-agent step.
+constexpr int CHAIN_SLOTS = 32;   // slots per pass (two passes per workgroup): tiles of 2 x 32 x (n + 1) doubles, 21 KB at
+                                  // n = 40 -- under the 38 KB of history the wave-per-agent blocks of the launch hold, so
+                                  // that four workgroups of either kind share a CU
 __device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w, int cb, int gpad, int par,
                                             int *__restrict__ lists_out, int *__restrict__ counts_out, double *lds)
 {
 #pragma clang fp contract(off)   // fixed roundings: the same bits as the wave-per-agent PH_W_LS_G
     const int n = c.n, N = c.N, ld = n + 1, t = threadIdx.x;
-    const int slot0 = cb * 64;
-    if (slot0 >= gpad) return;                           // uniform: no gradient slots here
-    double *tA = lds, *tB = lds + 64 * ld;
-    int *s_agent = (int *)(tB + 64 * ld);                // [0, 64): agent of the slot or -1; [64, 128): speculation issued
-    if (t < 64) {
-        const int uslot = slot0 + t;
-        const int raw = uslot < gpad ? w.agent_of[uslot] : -1;
-        const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0;
-        s_agent[t] = on ? (raw & AGENT_MASK) : -1;
-        s_agent[64 + t] = 0;
-    }
-    __syncthreads();
-    const int total = 64 * n;
-    for (int base = 0; base < total; base += 256 * 4) {  // gradient rows -> tile A, four loads in flight per thread
-        double v[4];
-        int off[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = base + u * 256 + t;
-            const int r = idx / n, j = idx - r * n;
-            const int ar = idx < total ? s_agent[r] : -1;
-            off[u] = ar >= 0 ? r * ld + j : -1;
-            v[u] = ar >= 0 ? w.ge[(size_t)ar * n + j] : 0.0;
+    if (cb * 64 >= gpad) return;                         // uniform: no gradient slots here
+    double *tA = lds, *tB = lds + CHAIN_SLOTS * ld;
+    int *s_agent = (int *)(tB + CHAIN_SLOTS * ld);       // [0, 32): agent of the slot or -1; [32, 64): speculation issued
+    const int total = CHAIN_SLOTS * n;
+    for (int pass = 0; pass < 64 / CHAIN_SLOTS; pass++) {
+        const int slot0 = cb * 64 + pass * CHAIN_SLOTS;
+        if (slot0 >= gpad) break;                        // uniform
+        __syncthreads();                                 // (the previous pass has left the tiles)
+        if (t < CHAIN_SLOTS) {
+            const int uslot = slot0 + t;
+            const int raw = uslot < gpad ? w.agent_of[uslot] : -1;
+            const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0;
+            s_agent[t] = on ? (raw & AGENT_MASK) : -1;
+            s_agent[CHAIN_SLOTS + t] = 0;
         }
+        __syncthreads();
+        for (int base = 0; base < total; base += 256 * 4) {  // gradient rows -> tile A, four loads in flight per thread
+            double v[4];
+            int off[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (off[u] >= 0) tA[off[u]] = v[u];
-    }
-    __syncthreads();
-    if (t < 64 && s_agent[t] >= 0) {
-        const int a = s_agent[t];
-        double *r = w.rec + (size_t)a * REC;
-        const double gm = r[R_GAMMAN];
-        const double *useq = w.useq + slot0 + t;
-        const size_t St = (size_t)w.St;
-        TreeSum sxx;                                     // speculate(): xx = sum of squares of the trial point
-        for (int k = N - 1; k >= 0; k--) {
-            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
-            sxx.add(k, 0.0 + x0 * x0, 0.0 + x1 * x1);
-        }
-        const double h = fd_step(sxx.total(n));
-        double *ga = tA + t * ld, *gb = tB + t * ld;
-        TreeSum spp, sgp;
-        int cnt = 0;
-        for (int k = N - 1; k >= 0; k--) {
-            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
-            const double g0 = ga[2 * k], g1 = ga[2 * k + 1];
-            const double p0 = prox_p(c, 0, x0, g0, gm), p1 = prox_p(c, 1, x1, g1, gm);   // prox_to_xe
-            ga[2 * k] = x0 + p0; ga[2 * k + 1] = x1 + p1;
-            spp.add(k, fma(p0, p0, 0.0), fma(p1, p1, 0.0));
-            sgp.add(k, fma(g0, p0, 0.0), fma(g1, p1, 0.0));
-            if (!c.no_spec) {                                                          // speculate()
-                const bool in0 = in_J(c, 0, x0, g0, gm), in1 = in_J(c, 1, x1, g1, gm);
-                cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
-                const double q0 = in0 ? 0.0 : p0, q1 = in1 ? 0.0 : p1;
-                gb[2 * k] = x0 + h * q0; gb[2 * k + 1] = x1 + h * q1;
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 256 + t;
+                const int r = idx / n, j = idx - r * n;
+                const int ar = idx < total ? s_agent[r] : -1;
+                off[u] = ar >= 0 ? r * ld + j : -1;
+                v[u] = ar >= 0 ? w.ge[(size_t)ar * n + j] : 0.0;
             }
-        }
-        const bool spec = !c.no_spec && cnt > 0 && cnt < n;
-        r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : r[R_PSIE];
-        r[R_PPN] = spp.total(n); r[R_GPN] = sgp.total(n);
-        r[R_SPEC] = spec ? 1.0 : 0.0;
-        if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
-        r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
-        r[R_PHASE] = (double)(PH_W_LS_C + chain_tag(par));
-        s_agent[64 + t] = spec ? 1 : 0;
-        const int pc = wave_append(&counts_out[1], true);
-        lists_out[(size_t)w.Ls + pc] = a;
-        const int pg = wave_append(&counts_out[0], spec);
-        if (spec) lists_out[pg] = a | CH2_BIT;
-    }
-    __syncthreads();
-    for (int base = 0; base < total; base += 256 * 4) {  // tiles -> xe rows (and xe2 rows where speculation was issued)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = base + u * 256 + t;
-            const int r = idx / n, j = idx - r * n;
-            const int ar = idx < total ? s_agent[r] : -1;
-            if (ar >= 0) {
-                w.xe[(size_t)ar * n + j] = tA[r * ld + j];
-                if (s_agent[64 + r]) w.xe2[(size_t)ar * n + j] = tB[r * ld + j];
+            for (int u = 0; u < 4; u++) if (off[u] >= 0) tA[off[u]] = v[u];
+        }
+        __syncthreads();
+        if (t < CHAIN_SLOTS && s_agent[t] >= 0) {
+            const int a = s_agent[t];
+            double *r = w.rec + (size_t)a * REC;
+            const double gm = r[R_GAMMAN];
+            const double *useq = w.useq + slot0 + t;
+            const size_t St = (size_t)w.St;
+            TreeSum sxx;                                     // speculate(): xx = sum of squares of the trial point
+            for (int k = N - 1; k >= 0; k--) {
+                const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
+                sxx.add(k, 0.0 + x0 * x0, 0.0 + x1 * x1);
+            }
+            const double h = fd_step(sxx.total(n));
+            double *ga = tA + t * ld, *gb = tB + t * ld;
+            TreeSum spp, sgp;
+            int cnt = 0;
+            for (int k = N - 1; k >= 0; k--) {
+                const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
+                const double g0 = ga[2 * k], g1 = ga[2 * k + 1];
+                const double p0 = prox_p(c, 0, x0, g0, gm), p1 = prox_p(c, 1, x1, g1, gm);   // prox_to_xe
+                ga[2 * k] = x0 + p0; ga[2 * k + 1] = x1 + p1;
+                spp.add(k, fma(p0, p0, 0.0), fma(p1, p1, 0.0));
+                sgp.add(k, fma(g0, p0, 0.0), fma(g1, p1, 0.0));
+                if (!c.no_spec) {                                                          // speculate()
+                    const bool in0 = in_J(c, 0, x0, g0, gm), in1 = in_J(c, 1, x1, g1, gm);
+                    cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+                    const double q0 = in0 ? 0.0 : p0, q1 = in1 ? 0.0 : p1;
+                    gb[2 * k] = x0 + h * q0; gb[2 * k + 1] = x1 + h * q1;
+                }
+            }
+            const bool spec = !c.no_spec && cnt > 0 && cnt < n;
+            r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : r[R_PSIE];
+            r[R_PPN] = spp.total(n); r[R_GPN] = sgp.total(n);
+            r[R_SPEC] = spec ? 1.0 : 0.0;
+            if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
+            r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
+            r[R_PHASE] = (double)(PH_W_LS_C + chain_tag(par));
+            s_agent[CHAIN_SLOTS + t] = spec ? 1 : 0;
+            const int pc = wave_append(&counts_out[1], true);
+            lists_out[(size_t)w.Ls + pc] = a;
+            const int pg = wave_append(&counts_out[0], spec);
+            if (spec) lists_out[pg] = a | CH2_BIT;
+        }
+        __syncthreads();
+        for (int base = 0; base < total; base += 256 * 4) {  // tiles -> xe rows (and xe2 rows where speculation was issued)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 256 + t;
+                const int r = idx / n, j = idx - r * n;
+                const int ar = idx < total ? s_agent[r] : -1;
+                if (ar >= 0) {
+                    w.xe[(size_t)ar * n + j] = tA[r * ld + j];
+                    if (s_agent[CHAIN_SLOTS + r]) w.xe2[(size_t)ar * n + j] = tB[r * ld + j];
+                }
             }
         }
     }
@@ -1179,11 +1200,17 @@ __device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w,
 // 4 waves walks 16 of them), collects their requests in LDS and appends them to the round's
 // gradient / cost work lists with one atomic per list, in agent order.
 constexpr int STEP_WAVES = 4;
+#ifndef MPC_STEP_WAVES_LEAN
+#define MPC_STEP_WAVES_LEAN 4
+#endif
 
-template <int NE, int MC>
-__global__ void __launch_bounds__(64 * STEP_WAVES, 2)
+// (the unconstrained one-element-per-lane variant with the history in LDS -- the benchmark's -- needs 133
+// registers: held to 128 it runs four waves per SIMD, with the LDS copy of the history capped at P pairs so that
+// four workgroups share a CU; every other variant keeps its two or three)
+template <int NE, int MC, bool HASM>
+__global__ void __launch_bounds__(64 * STEP_WAVES, (NE == 1 && MC < 0 && !HASM) ? MPC_STEP_WAVES_LEAN : 2)
 step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
-            int *__restrict__ counts_out, int *__restrict__ counts_next, int apb, int nstep, int par)
+            int *__restrict__ counts_out, int *__restrict__ counts_next, int apb, int nstep, int par, int P)
 {
     // blocks [0, nstep): the wave-per-agent state machine; blocks beyond (c.chain): PH_W_LS_G by one thread per
     // agent for the gradient slots of the round just finished, whose count K1c left in counts_next[2] (the buffer
@@ -1199,7 +1226,7 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     __shared__ int s_next;
     extern __shared__ double s_hist[];                   // MC < 0: 2 M n doubles per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *hist = s_hist + (MC < 0 ? (size_t)wv * 2 * c.M * c.n : 0);
+    double *hist = s_hist + (MC < 0 ? (size_t)wv * 2 * P * c.n : 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) { counts_next[0] = 0; counts_next[1] = 0; } // next round's buffer
     // Which of the workgroup's agents are still running: one coalesced look at their phase words.
     // Only the running ones are handed to the waves, so a wave never pays a memory round trip to
@@ -1246,12 +1273,12 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
             const int hl = hi | hf;
             const int sp = (int)rdlane(cur.rv, R_SPEC);
             if ((ph == PH_W_HESS || (ph == PH_W_LS_C && sp != 0)) && hl != 0) {
-                hist_dma(w.S + (size_t)a * c.M * c.n, w.Y + (size_t)a * c.M * c.n, hist, c.M * c.n,
+                hist_dma(w.S + (size_t)a * c.M * c.n, w.Y + (size_t)a * c.M * c.n, hist, P * c.n,
                          (hf ? c.M : hi) * c.n, lane);
                 hist_ready = true;
             }
         }
-        const int req = advance_agent<NE, MC>(c, w, a, lane, cur, hist, hist_ready, true, /*allow_chain=*/true);
+        const int req = advance_agent<NE, MC, HASM>(c, w, a, lane, cur, hist, hist_ready, true, /*allow_chain=*/true, P);
         if (lane == 0) s_req[loc] = req;
         loc = loc_next;
     }

@@ -340,9 +340,10 @@ def test_chained_step_and_selective_loads_are_bit_identical(dev, monkeypatch, mo
     as the same balanced trees the wavefront reductions form, speculation) and queues the follow-up requests
     itself, the agent skipping a step kernel (MPC_NO_CHAIN: the step kernel does it); (2) the step kernel
     fetches only the rows the agent's phase reads (MPC_ALL_ROWS: all six).  Same controls, multipliers and all
-    eight statistics columns, bit for bit -- with the persistent kernel taking over in mid-solve (agents whose
-    chained evaluation is still queued), from the start, and never; with and without speculation; with
-    constraints (m > 0); and for n = 80, where the chain is off by itself (two elements per lane)."""
+    eight statistics columns, bit for bit -- with the persistent kernel taking over in mid-solve, from the start,
+    and never; with and without speculation; with constraints (m > 0: the unspecialised kernel); for n = 80, where
+    the chain is off by itself (two elements per lane); and (3) with the LDS copy of the L-BFGS history capped
+    (the unconstrained kernel runs four waves per SIMD with 15 of 20 pairs in LDS; here 3, the rest from memory)."""
     x0 = synthetic_states(model, B, seed=23)
     if kw.get("constr_mode") == 2:
         x0[:, 1] = np.clip(x0[:, 1], -0.04, 0.04)
@@ -351,10 +352,10 @@ def test_chained_step_and_selective_loads_are_bit_identical(dev, monkeypatch, mo
     cfg = mp.default_config(model, N, **kw)
 
     def run(env, solo_max=None):
-        for k in ("MPC_NO_CHAIN", "MPC_ALL_ROWS", "MPC_NO_SPEC"):
+        for k in ("MPC_NO_CHAIN", "MPC_ALL_ROWS", "MPC_NO_SPEC", "MPC_LDS_PAIRS"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
-            monkeypatch.setenv(k, "1")
+            monkeypatch.setenv(k, "3" if k == "MPC_LDS_PAIRS" else "1")
         eng = mp.BatchedMPC(cfg, dev)
         if solo_max is not None:
             eng.set_solo_max(solo_max)
@@ -364,7 +365,9 @@ def test_chained_step_and_selective_loads_are_bit_identical(dev, monkeypatch, mo
     Ur, lr, sr, ir = run(("MPC_NO_CHAIN", "MPC_ALL_ROWS"))        # the round path of rounds 1 - 2
     assert (sr[:, 0] == 1).float().mean() >= 0.9
     for env, solo_max in (((), None), ((), 0), ((), 100000), (("MPC_NO_CHAIN",), None), (("MPC_ALL_ROWS",), None),
-                          (("MPC_NO_SPEC",), None), (("MPC_NO_SPEC",), 0)):
+                          (("MPC_NO_SPEC",), None), (("MPC_NO_SPEC",), 0),
+                          # the LDS copy of the L-BFGS history capped at 3 pairs: the rest from global memory
+                          (("MPC_LDS_PAIRS",), 0), (("MPC_LDS_PAIRS", "MPC_NO_CHAIN"), None)):
         U, lam, st, info = run(env, solo_max)
         assert torch.equal(U, Ur) and torch.equal(st, sr), (env, solo_max)
         assert (lam is None and lr is None) or torch.equal(lam, lr)
