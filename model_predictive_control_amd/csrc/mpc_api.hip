@@ -187,7 +187,9 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.no_spec = getenv("MPC_NO_SPEC") != nullptr;
     d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
     d.all_rows = getenv("MPC_ALL_ROWS") != nullptr;
-    d.chain = getenv("MPC_NO_CHAIN") == nullptr && 2 * c.N <= 64;
+    // (off by default: with the four-waves-per-SIMD step kernel of round 3 the thread-per-agent blocks no longer pay --
+    // 65 536 agents 387.0 k with them, 390.9 k without; 16 384 agents 198.6 k vs 207.3 k: profiles/r03_experiments.txt)
+    d.chain = getenv("MPC_CHAIN") != nullptr && 2 * c.N <= 64;
     d.h = c.Ts / c.nfe; d.v_ref = c.v_ref;
     for (int i = 0; i < 6; i++) { d.w[i] = c.cost_w[i]; d.g_off[i] = c.g_off[i]; d.D_lb[i] = c.D_lb[i]; d.D_ub[i] = c.D_ub[i]; }
     d.lf = c.veh[1]; d.lr = c.veh[2]; d.mass = c.veh[7]; d.inv_mass = 1.0 / c.veh[7]; d.inv_iz = 1.0 / c.veh[8];
