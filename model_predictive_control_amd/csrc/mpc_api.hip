@@ -38,7 +38,10 @@ struct mpc_handle {
     int wide_max = 4096;        // requests per round up to which K1a runs one wave per request (MPC_WIDE_MAX)
     int apb_env = 0;            // MPC_APB: agents per step-kernel workgroup (4, 16, 64; 0 = by batch size)
     bool fused_eval = true;     // K1b + K1c in one launch (MPC_UNFUSED_EVAL: the two-kernel path)
-    int fused_max = 16384;      // ... while a round holds at most this many requests (MPC_FUSED_MAX)
+    int fused_max = 1 << 30;    // ... while a round holds at most this many requests (MPC_FUSED_MAX).  Every round since the
+                                // step kernel's workgroups hold 38 KB of LDS instead of 51 (round 3): the fused kernel's
+                                // 44 KB workgroups now share a CU with them, and the stage records never leave LDS
+                                // (rounds 1 - 2: 16384 -- beyond that the two-kernel path was faster)
     bool arrive_adjoint = false; // MPC_ARRIVE: K1c inside K1b's last-arriving stage block instead of a launch of its own
                                  // (same bits; measured 3 % slower -- write-through record stores: DESIGN.md 6)
     int *arrive_buf = nullptr;  // arrival counters, one per block of 64 slots
