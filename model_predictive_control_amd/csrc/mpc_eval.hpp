@@ -209,7 +209,7 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 // 65 536 agents in three groups gives the thread-per-request kernel half a wave per SIMD: four times
 // the waves at 0.56 of the chain length fill the chip where it was idle, and shorten the chain where
 // a tail of few agents waits for it.  Same bits as rollout_kernel<PAC>.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, MPC_QUAD_WAVES)
 rollout_quad_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
                     const int *__restrict__ counts, int nG_imm, int nC_imm)
 {
@@ -531,11 +531,17 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
 #ifndef MPC_K1B_WAVES
 #define MPC_K1B_WAVES 3
 #endif
+#ifndef MPC_K1B_WAVES_PAC
+#define MPC_K1B_WAVES_PAC 1
+#endif
+#ifndef MPC_QUAD_WAVES
+#define MPC_QUAD_WAVES 2
+#endif
 // (tried: the gradient blocks and the cost blocks by kernels of their own -- the cost-only variant needs 55
 // registers and runs eight waves per SIMD, 13 us per launch against 75 us for the gradient blocks -- but
 // the pair of launches is slower than the one: 180.2 vs 175.6 ms per solve)
 template <int MODEL, bool SHARED_CL>
-__global__ void __launch_bounds__(64, (MODEL == KIN ? MPC_K1B_WAVES : 1))
+__global__ void __launch_bounds__(64, (MODEL == KIN ? MPC_K1B_WAVES : MPC_K1B_WAVES_PAC))
 stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
              int nblk_max)
 {
@@ -636,8 +642,11 @@ adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts
 // SPB consecutive slots per stage from the slot-indexed scratch.
 template <int MODEL> struct FusedBlk { static constexpr int BLK = MODEL == PAC ? 128 : 256; };
 
+#ifndef MPC_FUSED_WAVES
+#define MPC_FUSED_WAVES 3
+#endif
 template <int MODEL, bool SHARED_CL>
-__global__ void __launch_bounds__(FusedBlk<MODEL>::BLK, 2)
+__global__ void __launch_bounds__(FusedBlk<MODEL>::BLK, (MODEL == KIN ? MPC_FUSED_WAVES : 2))
 stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, int nG_imm, int nC_imm,
                      int *__restrict__ desc)
 {
