@@ -15,6 +15,15 @@
 #pragma once
 #include "mpc_solver.hpp"
 
+// occupancy the Pacejka kernels are compiled for (waves per SIMD); the values below are the measured best
+// (profiles/r03_experiments.txt 15: stage kernel at two 694 -> 730 ms per solve, four-lane rollout at three 694 -> 696)
+#ifndef MPC_K1B_WAVES_PAC
+#define MPC_K1B_WAVES_PAC 1
+#endif
+#ifndef MPC_QUAD_WAVES
+#define MPC_QUAD_WAVES 2
+#endif
+
 namespace mpc {
 
 // unified slot space of a round: gradient requests [0, nG), cost requests [gpad, gpad + nC),
@@ -531,12 +540,7 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
 #ifndef MPC_K1B_WAVES
 #define MPC_K1B_WAVES 3
 #endif
-#ifndef MPC_K1B_WAVES_PAC
-#define MPC_K1B_WAVES_PAC 1
-#endif
-#ifndef MPC_QUAD_WAVES
-#define MPC_QUAD_WAVES 2
-#endif
+
 // (tried: the gradient blocks and the cost blocks by kernels of their own -- the cost-only variant needs 55
 // registers and runs eight waves per SIMD, 13 us per launch against 75 us for the gradient blocks -- but
 // the pair of launches is slower than the one: 180.2 vs 175.6 ms per solve)
