@@ -97,7 +97,10 @@ class BatchedMPC:
             # (torch counts in-place writes in `_version`; the engine keeps the tensor alive meanwhile, so its
             # address cannot be handed to another table).  A table changed behind torch's back -- by a raw
             # kernel on its pointer -- needs `invalidate_centerline_tables()`.
-            key = (cl.data_ptr(), tuple(cl.shape), cl._version, self._nearest_blocks)
+            # (the stream is part of the key: the tables are built by kernels on the caller's current stream, and a
+            # call on another stream must not read them before those kernels have run)
+            key = (cl.data_ptr(), tuple(cl.shape), cl._version, self._nearest_blocks,
+                   torch.cuda.current_stream(self.device).cuda_stream)
             if key != self._cl_key:
                 self._cl_key, self._cl_keep = None, None
                 _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
