@@ -47,6 +47,10 @@ struct mpc_handle {
     int *arrive_buf = nullptr;  // arrival counters, one per block of 64 slots
     bool quad_rollout = true;   // K1a by two (kinematic) / four (Pacejka) lanes per request (MPC_NO_QUAD: one thread)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
+    int chain_min = 24576;      // MPC_CHAIN_MIN: requests bound of a group's round from which the thread-per-agent blocks
+                                // (chain_block) ride in its step launch.  Measured with the one-wave form (r03_experiments 18):
+                                // 65 536 agents (groups of 16 384) +1.2 % with them; 32 768 agents (groups of 10 923)
+                                // and 16 384 (groups of 8 192) -1 ... -2 %: only the full rounds of big groups
     int lds_pairs = 0;          // MPC_LDS_PAIRS: history pairs the step kernel's LDS copy holds (0 = chosen by launch_step_t)
     int num_cus = 256;
     // block bounding boxes of the centerline table last handed to mpc_centerline_blocks
@@ -190,9 +194,8 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.no_spec = getenv("MPC_NO_SPEC") != nullptr;
     d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
     d.all_rows = getenv("MPC_ALL_ROWS") != nullptr;
-    // (off by default: with the four-waves-per-SIMD step kernel of round 3 the thread-per-agent blocks no longer pay --
-    // 65 536 agents 387.0 k with them, 390.9 k without; 16 384 agents 198.6 k vs 207.3 k: profiles/r03_experiments.txt)
-    d.chain = getenv("MPC_CHAIN") != nullptr && 2 * c.N <= 64;
+    // (MPC_NO_CHAIN: never; which launches carry them is decided per launch: chain_min)
+    d.chain = getenv("MPC_NO_CHAIN") == nullptr && 2 * c.N <= 64;
     d.h = c.Ts / c.nfe; d.v_ref = c.v_ref;
     for (int i = 0; i < 6; i++) { d.w[i] = c.cost_w[i]; d.g_off[i] = c.g_off[i]; d.D_lb[i] = c.D_lb[i]; d.D_ub[i] = c.D_ub[i]; }
     d.lf = c.veh[1]; d.lr = c.veh[2]; d.mass = c.veh[7]; d.inv_mass = 1.0 / c.veh[7]; d.inv_iz = 1.0 / c.veh[8];
@@ -263,6 +266,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     mpc_handle *h = new mpc_handle();
     h->step_regs = getenv("MPC_STEP_REGS") != nullptr;
     if (getenv("MPC_LDS_PAIRS")) h->lds_pairs = atoi(getenv("MPC_LDS_PAIRS"));
+    if (getenv("MPC_CHAIN_MIN")) h->chain_min = atoi(getenv("MPC_CHAIN_MIN"));
     h->quad_rollout = getenv("MPC_NO_QUAD") == nullptr;
     h->arrive_adjoint = getenv("MPC_ARRIVE") != nullptr;
     if (getenv("MPC_WIDE_MAX")) h->wide_max = atoi(getenv("MPC_WIDE_MAX"));
@@ -719,11 +723,15 @@ static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int 
     size_t lds = MC < 0 ? (size_t)STEP_WAVES * 2 * P * h->dc.n * sizeof(double) : 0;
     // thread-per-agent blocks for the agents that wait in PH_W_LS_G (chain_block): one per 64 gradient slots the
     // finished round can have held (the same bound that sizes the K1 grids)
+    // ... only while the round is a full one: the thread-per-agent chain is ~15 us long whatever the count, which a
+    // step launch of > 100 us hides and a thin round's does not (chain_min: requests bound from which they are used)
     int nchain = 0;
-    if (NE == 1 && h->dc.chain) {
+    DevCfg dcl = h->dc;
+    dcl.chain = h->dc.chain && slot_bound >= h->chain_min;
+    if (NE == 1 && dcl.chain) {
         nchain = w.Bp / 64;
         if (slot_bound >= 0) nchain = std::min(nchain, (slot_bound + 126) / 64 + 1);
-        lds = std::max(lds, sizeof(double) * 2 * CHAIN_SLOTS * (size_t)(h->dc.n + 1) + sizeof(int) * 2 * CHAIN_SLOTS);
+        lds = std::max(lds, sizeof(double) * CHAIN_SLOTS * (size_t)(h->dc.n + 1) + sizeof(int) * CHAIN_SLOTS);
     }
     // agents per workgroup: 16 per wave fills the chip from ~50 k agents; smaller batches trade
     // throughput for latency (a wave walks its agents serially)
@@ -733,10 +741,10 @@ static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int 
     const int nstep = (w.B + apb - 1) / apb;
     if (h->dc.m == 0)
         hipLaunchKernelGGL((step_kernel<NE, MC, false>), dim3((unsigned)(nstep + nchain)), dim3(64 * STEP_WAVES), lds, s,
-                           h->dc, w, lists, counts, counts_next, apb, nstep, par, P);
+                           dcl, w, lists, counts, counts_next, apb, nstep, par, P);
     else
         hipLaunchKernelGGL((step_kernel<NE, MC, true>), dim3((unsigned)(nstep + nchain)), dim3(64 * STEP_WAVES), lds, s,
-                           h->dc, w, lists, counts, counts_next, apb, nstep, par, P);
+                           dcl, w, lists, counts, counts_next, apb, nstep, par, P);
 }
 static void launch_step(mpc_handle *h, const Workspace &w, hipStream_t s, int *lists, int *counts, int *counts_next,
                         int slot_bound, int par)

@@ -27,7 +27,8 @@ struct DevCfg {
     int max_num_initial_retries, max_num_retries, max_total_num_retries, max_total_inner, max_total_evals;
     int no_spec;         // MPC_NO_SPEC: no speculative gradients (same results, more rounds)
     int chain;           // agents that wait in PH_W_LS_G are served by one THREAD each, in extra workgroups of the
-                         // step-kernel launch (chain_block; n <= 64; on: MPC_CHAIN -- same results; default off)
+                         // step-kernel launch (chain_block; n <= 64; the host sets it per launch: full rounds of big
+                         // groups only; MPC_NO_CHAIN: never -- same results)
     int all_rows;        // MPC_ALL_ROWS: the step kernel fetches all six rows of an agent whatever its phase (same results)
     int no_memo;         // MPC_NO_MEMO / mpc_set_memo(h, 0): failed retries are recomputed, not replayed (same results)
     double h;      // RK4 step Ts / nfe

@@ -887,8 +887,9 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
             }
             XN = x;
             strow<NE>(w.xn + an, n, lane, x); strow<NE>(w.xe + an, n, lane, x);
-            // (round path: K1c runs PH_W_LS_G for this agent right behind the gradient, see CHAIN_BIT)
-            req = REQ_GRAD | (allow_chain && c.chain ? REQ_CHAIN : 0); phase = PH_W_LS_G;
+            // (round path: the entry is marked as "gradient at a trial point" whether or not the NEXT launch will
+            // carry thread-per-agent blocks -- the host decides that per launch -- see CHAIN_BIT)
+            req = REQ_GRAD | (allow_chain ? REQ_CHAIN : 0); phase = PH_W_LS_G;
         } break;
         case PH_W_LS_G: {
             psin = fallback ? (double)psixh : (double)psie;
@@ -1096,102 +1097,97 @@ __device__ __forceinline__ int wave_append(int *counter, bool on)
 // this round's lists, the record left as advance_agent leaves it -- with ONE THREAD per agent.  The gradient rows
 // come in through an LDS tile (coalesced, all four waves), the trial point from the slot-indexed useq scratch of
 // the finished round (coalesced; K1a of this round has not run yet), the results leave through the tiles again;
-// in two passes of 32 slots; half a wave does the arithmetic, 40 elements per lane, with the sums formed as the
-// wave reductions form them.
+// one wave does the arithmetic, 40 elements per lane, with the sums formed as the wave reductions form them.
 // ~2 000 wave-instructions per 64 slots, against ~350 per AGENT for the wave-per-agent step.
-constexpr int CHAIN_SLOTS = 32;   // slots per pass (two passes per workgroup): tiles of 2 x 32 x (n + 1) doubles, 21 KB at
-                                  // n = 40 -- under the 38 KB of history the wave-per-agent blocks of the launch hold, so
-                                  // that four workgroups of either kind share a CU
+constexpr int CHAIN_SLOTS = 64;   // slots per workgroup: one tile of 64 x (n + 1) doubles, 21 KB at n = 40 -- under the 38 KB of
+                                  // history the wave-per-agent blocks of the launch hold, so that four workgroups of either
+                                  // kind share a CU
 __device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w, int cb, int gpad, int par,
                                             int *__restrict__ lists_out, int *__restrict__ counts_out, double *lds)
 {
 #pragma clang fp contract(off)   // fixed roundings: the same bits as the wave-per-agent PH_W_LS_G
+    // ONE wave does the work of a chain block (the other three of the 256-thread workgroup leave at once and give
+    // their slots back: a thread per agent fills a wave with 64 agents, and a wave that only waits at barriers would
+    // hold registers the wave-per-agent blocks of the launch can use)
+    if (threadIdx.x >= 64) return;
     const int n = c.n, N = c.N, ld = n + 1, t = threadIdx.x;
-    if (cb * 64 >= gpad) return;                         // uniform: no gradient slots here
-    double *tA = lds, *tB = lds + CHAIN_SLOTS * ld;
-    int *s_agent = (int *)(tB + CHAIN_SLOTS * ld);       // [0, 32): agent of the slot or -1; [32, 64): speculation issued
+    const int slot0 = cb * CHAIN_SLOTS;
+    if (slot0 >= gpad) return;                           // uniform: no gradient slots here
+    double *tA = lds;
+    int *s_agent = (int *)(tA + CHAIN_SLOTS * ld);       // agent of the slot or -1
     const int total = CHAIN_SLOTS * n;
-    for (int pass = 0; pass < 64 / CHAIN_SLOTS; pass++) {
-        const int slot0 = cb * 64 + pass * CHAIN_SLOTS;
-        if (slot0 >= gpad) break;                        // uniform
-        __syncthreads();                                 // (the previous pass has left the tiles)
-        if (t < CHAIN_SLOTS) {
-            const int uslot = slot0 + t;
-            const int raw = uslot < gpad ? w.agent_of[uslot] : -1;
-            const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0;
-            s_agent[t] = on ? (raw & AGENT_MASK) : -1;
-            s_agent[CHAIN_SLOTS + t] = 0;
-        }
-        __syncthreads();
-        for (int base = 0; base < total; base += 256 * 4) {  // gradient rows -> tile A, four loads in flight per thread
-            double v[4];
-            int off[4];
+    {
+        const int uslot = slot0 + t;
+        const int raw = uslot < gpad ? w.agent_of[uslot] : -1;
+        const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0;
+        s_agent[t] = on ? (raw & AGENT_MASK) : -1;
+    }
+    __builtin_amdgcn_wave_barrier();                     // one wave: LDS is in order
+    for (int base = 0; base < total; base += 64 * 8) {   // gradient rows -> the tile (coalesced), eight loads in flight per lane
+        double v[8];
+        int off[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int idx = base + u * 256 + t;
-                const int r = idx / n, j = idx - r * n;
-                const int ar = idx < total ? s_agent[r] : -1;
-                off[u] = ar >= 0 ? r * ld + j : -1;
-                v[u] = ar >= 0 ? w.ge[(size_t)ar * n + j] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (off[u] >= 0) tA[off[u]] = v[u];
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * 64 + t;
+            const int r = idx / n, j = idx - r * n;
+            const int ar = idx < total ? s_agent[r] : -1;
+            off[u] = ar >= 0 ? r * ld + j : -1;
+            v[u] = ar >= 0 ? w.ge[(size_t)ar * n + j] : 0.0;
         }
-        __syncthreads();
-        if (t < CHAIN_SLOTS && s_agent[t] >= 0) {
-            const int a = s_agent[t];
-            double *r = w.rec + (size_t)a * REC;
-            const double gm = r[R_GAMMAN];
-            const double *useq = w.useq + slot0 + t;
-            const size_t St = (size_t)w.St;
-            TreeSum sxx;                                     // speculate(): xx = sum of squares of the trial point
-            for (int k = N - 1; k >= 0; k--) {
-                const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
-                sxx.add(k, 0.0 + x0 * x0, 0.0 + x1 * x1);
-            }
-            const double h = fd_step(sxx.total(n));
-            double *ga = tA + t * ld, *gb = tB + t * ld;
-            TreeSum spp, sgp;
-            int cnt = 0;
-            for (int k = N - 1; k >= 0; k--) {
-                const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
-                const double g0 = ga[2 * k], g1 = ga[2 * k + 1];
-                const double p0 = prox_p(c, 0, x0, g0, gm), p1 = prox_p(c, 1, x1, g1, gm);   // prox_to_xe
-                ga[2 * k] = x0 + p0; ga[2 * k + 1] = x1 + p1;
-                spp.add(k, fma(p0, p0, 0.0), fma(p1, p1, 0.0));
-                sgp.add(k, fma(g0, p0, 0.0), fma(g1, p1, 0.0));
-                if (!c.no_spec) {                                                          // speculate()
-                    const bool in0 = in_J(c, 0, x0, g0, gm), in1 = in_J(c, 1, x1, g1, gm);
-                    cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
-                    const double q0 = in0 ? 0.0 : p0, q1 = in1 ? 0.0 : p1;
-                    gb[2 * k] = x0 + h * q0; gb[2 * k + 1] = x1 + h * q1;
-                }
-            }
-            const bool spec = !c.no_spec && cnt > 0 && cnt < n;
-            r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : r[R_PSIE];
-            r[R_PPN] = spp.total(n); r[R_GPN] = sgp.total(n);
-            r[R_SPEC] = spec ? 1.0 : 0.0;
-            if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
-            r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
-            r[R_PHASE] = (double)(PH_W_LS_C + chain_tag(par));
-            s_agent[CHAIN_SLOTS + t] = spec ? 1 : 0;
-            const int pc = wave_append(&counts_out[1], true);
-            lists_out[(size_t)w.Ls + pc] = a;
-            const int pg = wave_append(&counts_out[0], spec);
-            if (spec) lists_out[pg] = a | CH2_BIT;
-        }
-        __syncthreads();
-        for (int base = 0; base < total; base += 256 * 4) {  // tiles -> xe rows (and xe2 rows where speculation was issued)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int idx = base + u * 256 + t;
-                const int r = idx / n, j = idx - r * n;
-                const int ar = idx < total ? s_agent[r] : -1;
-                if (ar >= 0) {
-                    w.xe[(size_t)ar * n + j] = tA[r * ld + j];
-                    if (s_agent[CHAIN_SLOTS + r]) w.xe2[(size_t)ar * n + j] = tB[r * ld + j];
-                }
+        for (int u = 0; u < 8; u++) if (off[u] >= 0) tA[off[u]] = v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int a = s_agent[t];
+    if (a >= 0) {
+        double *r = w.rec + (size_t)a * REC;
+        const double gm = r[R_GAMMAN];
+        const double *useq = w.useq + slot0 + t;
+        const size_t St = (size_t)w.St;
+        TreeSum sxx;                                     // speculate(): xx = sum of squares of the trial point
+        for (int k = N - 1; k >= 0; k--) {
+            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
+            sxx.add(k, 0.0 + x0 * x0, 0.0 + x1 * x1);
+        }
+        const double h = fd_step(sxx.total(n));
+        double *ga = tA + t * ld;
+        double *x2 = w.xe2 + (size_t)a * n;              // the speculative point goes straight to its row (16 bytes per stage)
+        TreeSum spp, sgp;
+        int cnt = 0;
+        for (int k = N - 1; k >= 0; k--) {
+            const double x0 = useq[(size_t)(2 * k) * St], x1 = useq[(size_t)(2 * k + 1) * St];
+            const double g0 = ga[2 * k], g1 = ga[2 * k + 1];
+            const double p0 = prox_p(c, 0, x0, g0, gm), p1 = prox_p(c, 1, x1, g1, gm);   // prox_to_xe
+            ga[2 * k] = x0 + p0; ga[2 * k + 1] = x1 + p1;
+            spp.add(k, fma(p0, p0, 0.0), fma(p1, p1, 0.0));
+            sgp.add(k, fma(g0, p0, 0.0), fma(g1, p1, 0.0));
+            if (!c.no_spec) {                                                          // speculate()
+                const bool in0 = in_J(c, 0, x0, g0, gm), in1 = in_J(c, 1, x1, g1, gm);
+                cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+                const double q0 = in0 ? 0.0 : p0, q1 = in1 ? 0.0 : p1;
+                x2[2 * k] = x0 + h * q0; x2[2 * k + 1] = x1 + h * q1;
             }
+        }
+        const bool spec = !c.no_spec && cnt > 0 && cnt < n;
+        r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : r[R_PSIE];
+        r[R_PPN] = spp.total(n); r[R_GPN] = sgp.total(n);
+        r[R_SPEC] = spec ? 1.0 : 0.0;
+        if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
+        r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
+        r[R_PHASE] = (double)(PH_W_LS_C + chain_tag(par));
+        const int pc = wave_append(&counts_out[1], true);
+        lists_out[(size_t)w.Ls + pc] = a;
+        const int pg = wave_append(&counts_out[0], spec);
+        if (spec) lists_out[pg] = a | CH2_BIT;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < total; base += 64 * 8) {   // the tile (now xhat+) -> xe rows
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * 64 + t;
+            const int r = idx / n, j = idx - r * n;
+            const int ar = idx < total ? s_agent[r] : -1;
+            if (ar >= 0) w.xe[(size_t)ar * n + j] = tA[r * ld + j];
         }
     }
 }

@@ -335,10 +335,11 @@ def test_shared_table_with_many_points(dev, O, model):
     (0, 12, 2500, dict(constr_mode=2, lane_halfwidth=0.05, max_total_inner=3000)),
     (0, 40, 1500, dict(max_total_inner=400))])
 def test_chained_step_and_selective_loads_are_bit_identical(dev, monkeypatch, model, N, B, kw):
-    """Round 3's changes to the round path against the path of rounds 1 - 2, on whole solves: (1) MPC_CHAIN: extra
-    workgroups of the step-kernel launch run PH_W_LS_G for the gradient of a line-search trial point by one THREAD
-    per agent (prox step, ||p||^2 and grad'p as the same balanced trees the wavefront reductions form, speculation)
-    instead of one wavefront (off by default: measured no faster once the step kernel ran four waves per SIMD);
+    """Round 3's changes to the round path against the path of rounds 1 - 2, on whole solves: (1) extra workgroups of
+    the step-kernel launch run PH_W_LS_G for the gradient of a line-search trial point by one THREAD per agent
+    (prox step, ||p||^2 and grad'p as the same balanced trees the wavefront reductions form, speculation) instead
+    of one wavefront -- in every launch (MPC_CHAIN_MIN=0), in the early launches only (a solve that starts with
+    them and goes on without), by default (full rounds of groups > 12 288 agents), never (MPC_NO_CHAIN);
     (2) the step kernel fetches only the rows the agent's phase reads (MPC_ALL_ROWS: all six).  Same controls, multipliers and all
     eight statistics columns, bit for bit -- with the persistent kernel taking over in mid-solve, from the start,
     and never; with and without speculation; with constraints (m > 0: the unspecialised kernel); for n = 80, where
@@ -352,22 +353,27 @@ def test_chained_step_and_selective_loads_are_bit_identical(dev, monkeypatch, mo
     cfg = mp.default_config(model, N, **kw)
 
     def run(env, solo_max=None):
-        for k in ("MPC_CHAIN", "MPC_ALL_ROWS", "MPC_NO_SPEC", "MPC_LDS_PAIRS"):
+        for k in ("MPC_NO_CHAIN", "MPC_CHAIN_MIN", "MPC_ALL_ROWS", "MPC_NO_SPEC", "MPC_LDS_PAIRS"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
-            monkeypatch.setenv(k, "3" if k == "MPC_LDS_PAIRS" else "1")
+            monkeypatch.setenv(k, {"MPC_LDS_PAIRS": "3", "MPC_CHAIN_MIN": "0", "MPC_CHAIN_MID": "0"}.get(k, "1"))
+        if "MPC_CHAIN_MID" in env:       # the blocks in the early (full) rounds only, then none
+            monkeypatch.delenv("MPC_CHAIN_MID")
+            monkeypatch.setenv("MPC_CHAIN_MIN", str(B))
         eng = mp.BatchedMPC(cfg, dev)
         if solo_max is not None:
             eng.set_solo_max(solo_max)
         U, lam, st = eng.solve(X0, cl, U0)
         return U, lam, st, eng.last_solve_info()
 
-    Ur, lr, sr, ir = run(("MPC_ALL_ROWS",))                        # the round path of rounds 1 - 2
+    Ur, lr, sr, ir = run(("MPC_NO_CHAIN", "MPC_ALL_ROWS"))        # the round path of rounds 1 - 2
     assert (sr[:, 0] == 1).float().mean() >= 0.9
-    for env, solo_max in (((), None), ((), 0), ((), 100000), (("MPC_CHAIN",), None), (("MPC_CHAIN",), 0),
-                          (("MPC_CHAIN", "MPC_ALL_ROWS"), None), (("MPC_NO_SPEC",), None), (("MPC_CHAIN", "MPC_NO_SPEC"), 0),
+    # (MPC_CHAIN_MIN=0: the thread-per-agent blocks in every launch -- by default only full rounds of big groups have them)
+    for env, solo_max in (((), None), ((), 0), ((), 100000), (("MPC_CHAIN_MIN",), None), (("MPC_CHAIN_MIN",), 0),
+                          (("MPC_CHAIN_MID",), 0), (("MPC_CHAIN_MIN", "MPC_ALL_ROWS"), None), (("MPC_NO_SPEC",), None),
+                          (("MPC_CHAIN_MIN", "MPC_NO_SPEC"), 0), (("MPC_NO_CHAIN",), None),
                           # the LDS copy of the L-BFGS history capped at 3 pairs: the rest from global memory
-                          (("MPC_LDS_PAIRS",), 0), (("MPC_LDS_PAIRS", "MPC_CHAIN"), None)):
+                          (("MPC_LDS_PAIRS", "MPC_NO_CHAIN"), 0), (("MPC_LDS_PAIRS", "MPC_CHAIN_MIN"), None)):
         U, lam, st, info = run(env, solo_max)
         assert torch.equal(U, Ur) and torch.equal(st, sr), (env, solo_max)
         assert (lam is None and lr is None) or torch.equal(lam, lr)

@@ -7,4 +7,4 @@ timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "cha
 rc=$?
 tail -30 $OUT/tests_chain.log
 if [ $rc -ne 0 ]; then echo "pytest rc $rc"; exit 4; fi
-bash tools_ab.sh ${1:-r03c} "" "MPC_CHAIN=1" ""
+bash tools_ab.sh ${1:-r03c} "" "MPC_NO_CHAIN=1" ""

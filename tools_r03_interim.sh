@@ -13,7 +13,7 @@ timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OU
 echo bench done
 # the two-handle pipeline with and without the thread-per-agent blocks, napping and spinning host loop
 Y="--no-cpu-baseline --no-kernel-pass --no-parity-leg --no-secondary --steps 8 --warmup 2"
-for V in "" "MPC_CHAIN=1" "MPC_SPIN=1"; do
+for V in "" "MPC_NO_CHAIN=1" "MPC_SPIN=1"; do
   env $V timeout -k 10 200 python bench.py $Y > $OUT/pipe.json 2> $OUT/pipe.err || { echo "pipe failed"; tail -5 $OUT/pipe.err; exit 5; }
   python - "$V" $OUT/pipe.json <<'PY'
 import json,sys
