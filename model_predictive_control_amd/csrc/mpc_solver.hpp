@@ -242,6 +242,19 @@ struct RecI { // an integer scalar of the record (stored as a double)
     __device__ __forceinline__ RecI &operator++(int) { return *this = (int)*this + 1; }
 };
 
+// The phase word and the iteration counter are read at every turn of the state machine's loop (two v_readlane, a
+// conversion and a v_readfirstlane each time): they are taken out of the record once per step and put back at its end
+// (round 3, with the kernel issue-bound at four waves per SIMD: step kernel 65.2 -> 62.9 ms per solve, 428.4 k -> 436.2 k
+// solves/s; the same with a dozen more scalars costs registers the kernel does not have: profiles/r03_experiments.txt).
+struct LocI {
+    int v; const int slot;
+    __device__ __forceinline__ LocI(double rv, int s) : v(__builtin_amdgcn_readfirstlane((int)rdlane(rv, s))), slot(s) {}
+    __device__ __forceinline__ operator int() const { return v; }
+    __device__ __forceinline__ LocI &operator=(int x) { v = x; return *this; }
+    __device__ __forceinline__ LocI &operator++(int) { v = v + 1; return *this; }
+    __device__ __forceinline__ void put(double &rv, int lane) const { rv = lane == slot ? (double)v : rv; }
+};
+
 // a row of n <= 64*NE doubles spread over the wave: element e of lane l is index l + 64 e
 template <int NE> struct Row { double v[NE]; };
 
@@ -553,8 +566,8 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     RecD out_eps{rv, lane, R_OUT_EPS};
     RecD out_delta{rv, lane, R_OUT_DELTA};
     RecD psi_out{rv, lane, R_PSI_OUT};
-    RecI phase{rv, lane, R_PHASE};
-    RecI k{rv, lane, R_K};
+    LocI phase(rv, R_PHASE);
+    LocI k(rv, R_K);
     RecI lidx{rv, lane, R_LIDX};
     RecI lfull{rv, lane, R_LFULL};
     RecI noprog{rv, lane, R_NOPROG};
@@ -1037,6 +1050,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     if ((req & (REQ_GRAD | REQ_COST)) != 0) nevals += 1; // speculative evaluations count when consumed
     if ((req & (REQ_GRAD | REQ_SPEC)) != 0) n_grad = 1;
 
+    phase.put(rv, lane); k.put(rv, lane);
     // write the record back (lane s stores slot s); the two counters accumulate over the solve
     rv += lane == R_NGRAD ? (double)n_grad : lane == R_LBROWS ? (double)lb_rows : lane == R_NSPEC ? (double)n_spec
         : lane == R_NSPEC_USED ? (double)n_used : lane == R_NCOST ? (double)((req & REQ_COST) != 0) : 0.0;
