@@ -195,7 +195,10 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
     d.all_rows = getenv("MPC_ALL_ROWS") != nullptr;
     // (MPC_NO_CHAIN: never; which launches carry them is decided per launch: chain_min)
-    d.chain = getenv("MPC_NO_CHAIN") == nullptr && 2 * c.N <= 64;
+    // (kinematic model only by default: measured on the Pacejka model, whose rounds wait for the rollout, 668 -> 699 ms per
+    // solve with them; MPC_CHAIN_MIN set explicitly turns them on for either model)
+    d.chain = getenv("MPC_NO_CHAIN") == nullptr && 2 * c.N <= 64 &&
+              (c.model == MPC_MODEL_KINEMATIC || getenv("MPC_CHAIN_MIN") != nullptr);
     d.h = c.Ts / c.nfe; d.v_ref = c.v_ref;
     for (int i = 0; i < 6; i++) { d.w[i] = c.cost_w[i]; d.g_off[i] = c.g_off[i]; d.D_lb[i] = c.D_lb[i]; d.D_ub[i] = c.D_ub[i]; }
     d.lf = c.veh[1]; d.lr = c.veh[2]; d.mass = c.veh[7]; d.inv_mass = 1.0 / c.veh[7]; d.inv_iz = 1.0 / c.veh[8];
