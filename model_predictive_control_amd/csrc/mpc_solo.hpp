@@ -114,7 +114,7 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
 __global__ void __launch_bounds__(256) solo_list_kernel(const Workspace w, int *__restrict__ list, int *__restrict__ ctr)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = a < w.B && w.rec[(size_t)a * REC + R_PHASE] != 0.0;
+    const bool on = a < w.B && rec_int_of(w.rec[(size_t)a * REC + R_PHASE]) != PH_DONE;
     const unsigned long long bal = __ballot(on);
     const int lane = threadIdx.x & 63;
     int base = 0;

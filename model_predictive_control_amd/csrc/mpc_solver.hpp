@@ -27,6 +27,16 @@ enum {
     R_RUN_MINEPS, R_RUN_EV0, R_MEMO_STATUS, R_MEMO_ITERS, R_MEMO_EVALS, R_MEMO_MINEPS, R_MEMO_EPS, R_USED
 };
 static_assert(R_USED <= REC, "record too small");
+// The integers of the record (phase, counters, flags: all >= 0) are stored as the double 2^52 + k, whose low dword IS
+// k: a read is one v_readlane, a write one v_cndmask of the low dword -- as (double)k they cost two v_readlane, a
+// v_cvt_i32_f64 and a v_readfirstlane per read, and the state machine reads ~30 of them per step (round 3: the step
+// kernel is issue-bound at four waves per SIMD).  R_NGRAD .. R_NCOST are plain double counters (they are only added to).
+__host__ __device__ constexpr bool rec_is_int(int s)
+{
+    return (s >= R_PHASE && s <= R_OUT_OF_ITER) || s == R_SPEC || (s >= R_RUN_EV0 && s <= R_MEMO_EVALS);
+}
+__device__ __forceinline__ double rec_int(int k) { return __hiloint2double(0x43300000, k); }
+__device__ __forceinline__ int rec_int_of(double v) { return __double2loint(v); }
 
 enum Phase {
     PH_DONE = 0,
@@ -231,11 +241,15 @@ struct RecD { // a double scalar of the agent record, held in lane `slot` of the
     __device__ __forceinline__ RecD &operator*=(double x) { return *this = (double)*this * x; }
     __device__ __forceinline__ RecD &operator/=(double x) { return *this = (double)*this / x; }
 };
-struct RecI { // an integer scalar of the record (stored as a double)
+struct RecI { // an integer scalar of the record (stored as 2^52 + k: rec_int)
     double &rv; const int lane, slot;
-    __device__ __forceinline__ operator int() const
-    { return __builtin_amdgcn_readfirstlane((int)rdlane(rv, slot)); }
-    __device__ __forceinline__ RecI &operator=(int x) { rv = lane == slot ? (double)x : rv; return *this; }
+    __device__ __forceinline__ operator int() const { return __builtin_amdgcn_readlane(__double2loint(rv), slot); }
+    __device__ __forceinline__ RecI &operator=(int x)
+    {
+        const int lo = __double2loint(rv);
+        rv = __hiloint2double(__double2hiint(rv), lane == slot ? x : lo);
+        return *this;
+    }
     __device__ __forceinline__ RecI &operator=(const RecI &o) { return *this = (int)o; }
     __device__ __forceinline__ RecI &operator+=(int x) { return *this = (int)*this + x; }
     __device__ __forceinline__ RecI &operator|=(int x) { return *this = (int)*this | x; }
@@ -248,11 +262,12 @@ struct RecI { // an integer scalar of the record (stored as a double)
 // solves/s; the same with a dozen more scalars costs registers the kernel does not have: profiles/r03_experiments.txt).
 struct LocI {
     int v; const int slot;
-    __device__ __forceinline__ LocI(double rv, int s) : v(__builtin_amdgcn_readfirstlane((int)rdlane(rv, s))), slot(s) {}
+    __device__ __forceinline__ LocI(double rv, int s) : v(__builtin_amdgcn_readlane(__double2loint(rv), s)), slot(s) {}
     __device__ __forceinline__ operator int() const { return v; }
     __device__ __forceinline__ LocI &operator=(int x) { v = x; return *this; }
     __device__ __forceinline__ LocI &operator++(int) { v = v + 1; return *this; }
-    __device__ __forceinline__ void put(double &rv, int lane) const { rv = lane == slot ? (double)v : rv; }
+    __device__ __forceinline__ void put(double &rv, int lane) const
+    { rv = __hiloint2double(__double2hiint(rv), lane == slot ? v : __double2loint(rv)); }
 };
 
 // a row of n <= 64*NE doubles spread over the wave: element e of lane l is index l + 64 e
@@ -534,7 +549,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     // coherent with memory, so a chain of phases never re-reads a row it has just written.
     double rv = in.rv;
     Row<NE> X = in.X, G = in.G, GE = in.GE, Q = in.Q, XN = in.XN;
-    if ((int)rdlane(rv, R_PHASE) == PH_DONE) return REQ_NONE;
+    if (__builtin_amdgcn_readlane(__double2loint(rv), R_PHASE) == PH_DONE) return REQ_NONE;
     // The ~50 per-agent scalars stay where they arrive: slot s of the record in lane s of `rv`.
     // A scalar is read with v_readlane when a phase needs it and written back into its lane;
     // a phase touches a handful of them, so nothing is unpacked or repacked wholesale.
@@ -1183,12 +1198,12 @@ __device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w,
             }
         }
         const bool spec = !c.no_spec && cnt > 0 && cnt < n;
-        r[R_PSIN] = r[R_FALLBACK] != 0.0 ? r[R_PSIXH] : r[R_PSIE];
+        r[R_PSIN] = rec_int_of(r[R_FALLBACK]) != 0 ? r[R_PSIXH] : r[R_PSIE];
         r[R_PPN] = spp.total(n); r[R_GPN] = sgp.total(n);
-        r[R_SPEC] = spec ? 1.0 : 0.0;
+        r[R_SPEC] = rec_int(spec ? 1 : 0);
         if (spec) { r[R_SPEC_GAMMA] = gm; r[R_NSPEC] += 1.0; r[R_NGRAD] += 1.0; }
-        r[R_NEVALS] += 1.0; r[R_NCOST] += 1.0;
-        r[R_PHASE] = (double)(PH_W_LS_C + chain_tag(par));
+        r[R_NEVALS] = rec_int(rec_int_of(r[R_NEVALS]) + 1); r[R_NCOST] += 1.0;
+        r[R_PHASE] = rec_int(PH_W_LS_C + chain_tag(par));
         const int pc = wave_append(&counts_out[1], true);
         lists_out[(size_t)w.Ls + pc] = a;
         const int pg = wave_append(&counts_out[0], spec);
@@ -1242,9 +1257,9 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     // Only the running ones are handed to the waves, so a wave never pays a memory round trip to
     // find out that an agent is finished.
     const int base = blockIdx.x * apb;
-    const double phw = lane < apb && base + lane < w.B ? w.rec[(size_t)(base + lane) * REC + R_PHASE] : 0.0;
+    const int phw = lane < apb && base + lane < w.B ? rec_int_of(w.rec[(size_t)(base + lane) * REC + R_PHASE]) : 0;
     // (PH_DONE == 0; with c.chain an agent that waits in PH_W_LS_G is served by a chain_block of this launch)
-    const bool runnable = phw != 0.0 && !(c.chain && (phw == (double)PH_W_LS_G || phw == (double)(PH_W_LS_C + chain_tag(par))));
+    const bool runnable = phw != 0 && !(c.chain && (phw == PH_W_LS_G || phw == PH_W_LS_C + chain_tag(par)));
     const unsigned long long act = __ballot(runnable);
     const int rank = __popcll(act & ((1ull << lane) - 1ull));
     const int nact = __popcll(act);
@@ -1264,7 +1279,7 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     AgentIn<NE> nxt;
     int loc = claim();
     // (MPC_ALL_ROWS: the six-row fetch of rounds 1 - 2, for the A/B measurement and the bit-identity test)
-    const auto phase_of = [&](int l) { return c.all_rows ? -1 : ((int)rdlane(phw, l) & PH_MASK); };
+    const auto phase_of = [&](int l) { return c.all_rows ? -1 : (__builtin_amdgcn_readlane(phw, l) & PH_MASK); };
     if (loc >= 0) nxt = load_agent<NE>(c, w, base + loc, lane, phase_of(loc));
     while (loc >= 0) {
         const int a = base + loc;
@@ -1278,10 +1293,11 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
             // LDS-DMA of its history now.  Issued BEHIND the next agent's row loads: the wait for the
             // history drains the wave's vector-memory queue in order, so nothing younger than what it
             // needs should be in it.
-            const int ph = (int)rdlane(cur.rv, R_PHASE) & PH_MASK;
-            const int hi = (int)rdlane(cur.rv, R_LIDX), hf = (int)rdlane(cur.rv, R_LFULL);
+            const int rlo = __double2loint(cur.rv);      // (the integers of the record: rec_int)
+            const int ph = __builtin_amdgcn_readlane(rlo, R_PHASE) & PH_MASK;
+            const int hi = __builtin_amdgcn_readlane(rlo, R_LIDX), hf = __builtin_amdgcn_readlane(rlo, R_LFULL);
             const int hl = hi | hf;
-            const int sp = (int)rdlane(cur.rv, R_SPEC);
+            const int sp = __builtin_amdgcn_readlane(rlo, R_SPEC);
             if ((ph == PH_W_HESS || (ph == PH_W_LS_C && sp != 0)) && hl != 0) {
                 hist_dma(w.S + (size_t)a * c.M * c.n, w.Y + (size_t)a * c.M * c.n, hist, P * c.n,
                          (hf ? c.M : hi) * c.n, lane);
@@ -1319,7 +1335,7 @@ __global__ void init_kernel(const DevCfg c, const Workspace w)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per record slot
     const int a = (int)(i / REC), slot = (int)(i % REC);
     if (a >= w.B) return;
-    double v = 0.0;
+    double v = rec_is_int(slot) ? rec_int(0) : 0.0;
     switch (slot) {
     case R_EPS: v = c.eps0; break;
     case R_EPS_OLD: v = NAN; break;
@@ -1328,8 +1344,8 @@ __global__ void init_kernel(const DevCfg c, const Workspace w)
     case R_NE1: v = NAN; break;
     case R_OUT_EPS: v = INFINITY; break;
     case R_OUT_DELTA: v = INFINITY; break;
-    case R_FIRST: v = 1.0; break;
-    case R_PHASE: v = c.max_outer > 0 ? (double)PH_OUTER_BEGIN : (double)PH_DONE; break;
+    case R_FIRST: v = rec_int(1); break;
+    case R_PHASE: v = rec_int(c.max_outer > 0 ? PH_OUTER_BEGIN : PH_DONE); break;
     default: break;
     }
     w.rec[i] = v;
@@ -1348,7 +1364,7 @@ __global__ void __launch_bounds__(256) totals_kernel(const Workspace w)
     if (a < w.B) {
         const double *r = w.rec + (size_t)a * REC;
         ng = r[R_NGRAD]; nc = r[R_NCOST]; lr = r[R_LBROWS]; ns = r[R_NSPEC]; nu = r[R_NSPEC_USED];
-        unfinished = r[R_PHASE] != (double)PH_DONE;
+        unfinished = rec_int_of(r[R_PHASE]) != PH_DONE;
     }
     ng = wave_sum(ng); nc = wave_sum(nc); lr = wave_sum(lr); ns = wave_sum(ns); nu = wave_sum(nu);
     const unsigned long long unf = __ballot(unfinished);
@@ -1369,8 +1385,9 @@ __global__ void stats_kernel(const Workspace w, double *__restrict__ stats)
     if (a >= w.B) return;
     const double *r = w.rec + (size_t)a * REC;
     double *s = stats + (size_t)a * 8;
-    s[0] = r[R_STATUS]; s[1] = r[R_OUTER]; s[2] = r[R_INNER_TOT]; s[3] = r[R_INNER_FAIL];
-    s[4] = r[R_OUT_EPS]; s[5] = r[R_OUT_DELTA]; s[6] = r[R_PSI_OUT]; s[7] = r[R_NEVALS];
+    s[0] = (double)rec_int_of(r[R_STATUS]); s[1] = (double)rec_int_of(r[R_OUTER]);
+    s[2] = (double)rec_int_of(r[R_INNER_TOT]); s[3] = (double)rec_int_of(r[R_INNER_FAIL]);
+    s[4] = r[R_OUT_EPS]; s[5] = r[R_OUT_DELTA]; s[6] = r[R_PSI_OUT]; s[7] = (double)rec_int_of(r[R_NEVALS]);
 }
 
 } // namespace mpc
