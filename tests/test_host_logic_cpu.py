@@ -76,3 +76,51 @@ def test_bezier_mirror_matches_reference_fixture(ref_golden):
     tab = bc.lane_change_centerlines(S=100)
     assert tab.shape == (10, 200) and np.allclose(tab[:, 0], 0) and np.allclose(tab[:, 99], 10.0)
     assert np.allclose(tab[:, 199], 3.75 * 10.0 / 193.76417765201978)
+
+
+def _wave_sum_order(v, n):
+    """The order in which the wavefront reductions of csrc/mpc_solver.hpp add a vector with element j on lane j
+    (row_sum16: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror inside every 16-lane row, then
+    cross_rows<NROWS(n)>), replayed lane by lane in IEEE doubles."""
+    x = np.zeros(64)
+    x[:n] = v
+    for partner in (lambda l: l ^ 1, lambda l: l ^ 2, lambda l: (l & ~7) | (7 - (l & 7)), lambda l: (l & ~15) | (15 - (l & 15))):
+        x = np.array([x[l] + x[partner(l)] for l in range(64)])
+    r = [x[0], x[16], x[32], x[48]]
+    assert all(np.all(x[16 * i:16 * i + 16] == r[i]) for i in range(4))       # every lane of a row holds the row total
+    return r[0] + r[1] if n <= 32 else (r[0] + r[1]) + r[2] if n <= 48 else (r[0] + r[1]) + (r[2] + r[3])
+
+
+def _tree_sum_by_stages(v, n):
+    """TreeSum of csrc/mpc_solver.hpp (the thread-per-agent PH_W_LS_G, chain_block): the same vector met two elements
+    at a time -- stage k = elements 2k, 2k + 1 -- in DESCENDING stage order, with three holders."""
+    h1 = h2 = h3 = 0.0
+    r = [0.0, 0.0, 0.0, 0.0]
+    for k in range(n // 2 - 1, -1, -1):
+        t = v[2 * k] + v[2 * k + 1]
+        if k & 1:
+            h1 = t; continue
+        q = t + h1; h1 = 0.0
+        if k & 2:
+            h2 = q; continue
+        hf = q + h2; h2 = 0.0
+        if k & 4:
+            h3 = hf; continue
+        r[k >> 3] = hf + h3; h3 = 0.0
+    return r[0] + r[1] if n <= 32 else (r[0] + r[1]) + r[2] if n <= 48 else (r[0] + r[1]) + (r[2] + r[3])
+
+
+def test_thread_serial_tree_sum_has_the_bits_of_the_wave_reduction():
+    """The thread-per-agent form of PH_W_LS_G must give the wavefront form's ||p||^2, grad'p and ||x||^2 bit for bit:
+    both are balanced trees over the lanes in lane order -- checked here on the host for every horizon 1 .. 32 with
+    values of mixed sign and magnitude (where any other order of additions rounds differently)."""
+    rng = np.random.default_rng(0)
+    differs_from_sequential = 0
+    for N in range(1, 33):
+        n = 2 * N
+        for _ in range(20):
+            v = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, n)
+            a, b = _wave_sum_order(v, n), _tree_sum_by_stages(v, n)
+            assert a == b and np.signbit(a) == np.signbit(b), (N, a, b)
+            differs_from_sequential += a != float(np.add.reduce(v))
+    assert differs_from_sequential > 100          # (the test can tell orders apart)
