@@ -933,6 +933,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     }
     int rc_loop = MPC_OK;
     double host_queue_s = 0.0;                  // host time spent queueing launches (MPC_HOST_TIMING: printed at the end)
+    long long dry_windows = 0, first_dry_round = -1;
     static const bool host_timing = getenv("MPC_HOST_TIMING") != nullptr;
     const auto t_loop0 = std::chrono::steady_clock::now();
     auto queue_window_impl = [&](int g) {       // `check_every` rounds of group g, then the copy of its counters
@@ -1015,6 +1016,10 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             if (q == hipErrorNotReady) continue;
             if (q != hipSuccess) { rc_loop = MPC_E_HIP; break; }
             progressed = true;
+            if (host_timing && r.window - oldest > 1 && hipEventQuery(h->pollev[pb ^ 1][g]) == hipSuccess) {
+                // both queued windows have run: this group's stream was empty while the host was elsewhere
+                if (dry_windows++ == 0) first_dry_round = r.round;
+            }
             bool go = decide(g, pb);
             if (go && r.round >= max_rounds) {
                 // the round limit: nothing more can be queued; the verdict is the LAST window's
@@ -1034,9 +1039,10 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
     if (host_timing)
-        fprintf(stderr, "[mpc host] round loop %.2f ms, of which queueing launches %.2f ms (%lld launch sets, %d groups)\n",
+        fprintf(stderr, "[mpc host] round loop %.2f ms, of which queueing launches %.2f ms (%lld launch sets, %d groups); "
+                        "windows found with the stream already empty: %lld (first at round %lld)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(),
-                host_queue_s * 1e3, launch_sets, ng);
+                host_queue_s * 1e3, launch_sets, ng, dry_windows, first_dry_round);
     if (rc_loop == MPC_E_LIMIT) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
     if (rc_loop != MPC_OK) return fail(rc_loop, "mpc_solve_batch: HIP error in the round loop");
     {

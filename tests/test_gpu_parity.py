@@ -195,6 +195,7 @@ def test_failed_retries_are_replayed_not_recomputed(dev, O):
     Uo, _, so = O.solve_batch(ocfg, x_stall, cl_np, U0, nthreads=1)
     assert so[0, 0] == 1 and so[0, 1] >= 30                     # the oracle: converged after the retries
     eng = mp.BatchedMPC(cfg, dev)
+    eng.set_memo(True)                                          # the subject of this test, whatever MPC_NO_MEMO says
     U1, _, s1 = eng.solve(T(x_stall, dev), cl, T(U0, dev))
     info = eng.last_solve_info()
     s1 = s1.cpu().numpy()
@@ -751,6 +752,7 @@ def test_step_kernel_variants_are_bit_identical(dev, monkeypatch):
     M n <= 800) or in registers (MPC_STEP_REGS / larger n): same arithmetic, same order, so the
     two give the same bits; N = 32 (n = 64) takes the register variant by itself."""
     monkeypatch.setenv("MPC_SOLO_MAX", "0")      # the round path (the persistent kernel has its own test)
+    monkeypatch.delenv("MPC_NO_SPEC", raising=False)   # (the speculation counters below are part of the subject)
     B, N = 300, 20
     X0 = T(synthetic_states(0, B, seed=5), dev)
     cl = T(straight_centerline(), dev)
