@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <array>
 #include <vector>
 
 using namespace mpc;
@@ -410,7 +411,7 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
     bool quad = false;
     if constexpr (MODEL == KIN) {
         // two lanes per request (rollout_pair_kernel); the wave-per-request kernel keeps the rounds with few requests
-        quad = !wide && h->quad_rollout && c.nfe == 4;
+        quad = !wide && h->quad_rollout && c.nfe == 4 && c.N <= 64;   // (its wave-wide redo of a request: kin_wide_rollout)
         if (quad)
             hipLaunchKernelGGL(rollout_pair_kernel, dim3((unsigned)(nblk * 2)), dim3(64),
                                sizeof(double) * 32 * (size_t)(c.n + 1), s, c, w, lists, counts, nG, nC);
@@ -934,6 +935,8 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     int rc_loop = MPC_OK;
     double host_queue_s = 0.0;                  // host time spent queueing launches (MPC_HOST_TIMING: printed at the end)
     long long dry_windows = 0, first_dry_round = -1;
+    static const char *host_trace = getenv("MPC_HOST_TRACE");   // file: one line per polled window (group, round, us, requests)
+    std::vector<std::array<long long, 4>> trace;
     static const bool host_timing = getenv("MPC_HOST_TIMING") != nullptr;
     const auto t_loop0 = std::chrono::steady_clock::now();
     auto queue_window_impl = [&](int g) {       // `check_every` rounds of group g, then the copy of its counters
@@ -1020,6 +1023,10 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
                 // both queued windows have run: this group's stream was empty while the host was elsewhere
                 if (dry_windows++ == 0) first_dry_round = r.round;
             }
+            if (host_trace)
+                trace.push_back({(long long)g, r.round - (r.window - oldest) * check_every + check_every - 1,
+                                 (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count(),
+                                 (long long)(h->host_counts[16 * pb + 2 * g] + h->host_counts[16 * pb + 2 * g + 1])});
             bool go = decide(g, pb);
             if (go && r.round >= max_rounds) {
                 // the round limit: nothing more can be queued; the verdict is the LAST window's
@@ -1043,6 +1050,13 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
                         "windows found with the stream already empty: %lld (first at round %lld)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(),
                 host_queue_s * 1e3, launch_sets, ng, dry_windows, first_dry_round);
+    if (host_trace) {
+        if (FILE *f = fopen(host_trace, "a")) {
+            fprintf(f, "# solve: group, last round of the window, us since the loop began, requests of that round\n");
+            for (const auto &t : trace) fprintf(f, "%lld %lld %lld %lld\n", t[0], t[1], t[2], t[3]);
+            fclose(f);
+        }
+    }
     if (rc_loop == MPC_E_LIMIT) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
     if (rc_loop != MPC_OK) return fail(rc_loop, "mpc_solve_batch: HIP error in the round loop");
     {
@@ -1322,3 +1336,11 @@ extern "C" int mpc_set_profile(mpc_handle *h, int on)
     h->profile = on != 0;
     return MPC_OK;
 }
+
+#ifdef MPC_DEV_K1A_TIMES
+extern "C" int mpc_dev_k1a_times(long long *host_out)    // (timing experiment) the stamps of the last K1a launch
+{
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mpc::g_k1a_times), sizeof(long long) * 4 * 16384) == hipSuccess ? 0 : 1;
+}
+#endif

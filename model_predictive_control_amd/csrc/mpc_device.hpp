@@ -611,6 +611,41 @@ MPC_DEV void kin_increment(const DevCfg &c, const StageInput<KIN> &u, double ph,
     dy = h6 * (fma(2.0, k3y, fma(2.0, k2y, k1y)) + k4y);
 }
 
+// The same three pieces with the roundings of stage_forward_steps<KIN> (products and sums kept apart, the
+// sin/cos pairs of step_trig), which is what a stage OUTSIDE the fast range (kin4_in_range) is computed by:
+// the wave-per-request rollout serves such stages too, bit for bit, instead of handing the whole request to
+// one lane.  kin_gen_rk: the speed / heading stage values of one RK4 step; kin_gen_next: the step to the next
+// (heading, speed); kin_gen_increment: the position increment.
+MPC_DEV void kin_gen_rk(const DevCfg &c, const StageInput<KIN> &u, double v, KinRK &k)
+{
+#pragma clang fp contract(off)
+    const double h = c.h, hh = 0.5 * h;
+    k.v1 = v;               k.kv1 = u.ad - c.friction * k.v1; k.kp1 = k.v1 * u.sb_lr;
+    k.v2 = v + hh * k.kv1;  k.kv2 = u.ad - c.friction * k.v2; k.kp2 = k.v2 * u.sb_lr;
+    k.v3 = v + hh * k.kv2;  k.kv3 = u.ad - c.friction * k.v3; k.kp3 = k.v3 * u.sb_lr;
+    k.v4 = v + h * k.kv3;   k.kv4 = u.ad - c.friction * k.v4; k.kp4 = k.v4 * u.sb_lr;
+}
+MPC_DEV void kin_gen_next(const DevCfg &c, const KinRK &k, double &ph, double &v)
+{
+#pragma clang fp contract(off)
+    const double h = c.h;
+    ph = ph + (h / 6.0) * (k.kp1 + 2.0 * k.kp2 + 2.0 * k.kp3 + k.kp4);
+    v = v + (h / 6.0) * (k.kv1 + 2.0 * k.kv2 + 2.0 * k.kv3 + k.kv4);
+}
+MPC_DEV void kin_gen_increment(const DevCfg &c, const StageInput<KIN> &u, double ph, double v, const KinRK &k,
+                               double &dx, double &dy)
+{
+#pragma clang fp contract(off)
+    const double h = c.h;
+    const double x[4] = {0.0, 0.0, ph, v};
+    StepTrig tr;
+    step_trig(c, u, x, tr);
+    const double k1x = k.v1 * tr.sc[0].c, k2x = k.v2 * tr.sc[1].c, k3x = k.v3 * tr.sc[2].c, k4x = k.v4 * tr.sc[3].c;
+    const double k1y = k.v1 * tr.sc[0].s, k2y = k.v2 * tr.sc[1].s, k3y = k.v3 * tr.sc[2].s, k4y = k.v4 * tr.sc[3].s;
+    dx = (h / 6.0) * (k1x + 2.0 * k2x + 2.0 * k3x + k4x);
+    dy = (h / 6.0) * (k1y + 2.0 * k2y + 2.0 * k3y + k4y);
+}
+
 MPC_DEV void stage_forward_kin4(const DevCfg &c, const StageInput<KIN> &u, double (&x)[4], bool ok_in)
 {
 #pragma clang fp contract(off)
@@ -641,7 +676,11 @@ MPC_DEV bool kin4_in_range(const DevCfg &c, const StageInput<KIN> &u, const doub
     const double vmax = fabs(x[3]) + 2.0 * Ts * (fabs(u.ad) + fabs(c.friction * x[3]));
     const double dmax = c.h * vmax * fabs(u.sb_lr);
     const double amax = fabs(x[2]) + fabs(u.beta) + 4.0 * dmax;
+#ifdef MPC_DEV_ALWAYS_IN_RANGE
+    return amax == amax || true;                         // (timing experiment: what do the out-of-range lanes cost? WRONG results for them)
+#else
     return dmax <= 0.7 && amax < 1.0e5 && fabs(c.friction) * Ts <= 0.5;
+#endif
 }
 
 template <int MODEL>

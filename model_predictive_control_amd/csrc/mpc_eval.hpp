@@ -111,11 +111,32 @@ rollout_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
 #ifndef MPC_K1A_WAVES
 #define MPC_K1A_WAVES 3
 #endif
+template <class Put>
+__device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double (&x0)[4], double d, double dl, int lane, Put put);
+#ifdef MPC_DEV_K1A_TIMES
+__device__ long long g_k1a_times[4 * 16384];             // (timing experiment) per workgroup: start, end (100 MHz clock), HW_ID, XCC_ID
+struct K1aStamp {
+    long long t0; int blk; int nfall = 0, nmid = 0, nslow = 0;
+    __device__ K1aStamp(int b) : t0(__builtin_amdgcn_s_memrealtime()), blk(b) {}
+    __device__ ~K1aStamp()
+    {
+        if (threadIdx.x == 0 && blk < 16384) {
+            g_k1a_times[4 * blk] = t0; g_k1a_times[4 * blk + 1] = __builtin_amdgcn_s_memrealtime();
+            g_k1a_times[4 * blk + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+            g_k1a_times[4 * blk + 3] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15)  // XCC_ID
+                                       | ((long long)nfall << 8) | ((long long)nmid << 16) | ((long long)nslow << 24);
+        }
+    }
+};
+#endif
 __global__ void __launch_bounds__(64, MPC_K1A_WAVES)
 rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
                     const int *__restrict__ counts, int nG_imm, int nC_imm)
 {
 #pragma clang fp contract(off)
+#ifdef MPC_DEV_K1A_TIMES
+    K1aStamp stamp(blockIdx.x);
+#endif
     constexpr int RPB = 32;                              // requests per block
     extern __shared__ double lds[];                      // [RPB][n + 1] control rows
     const SlotMap sm(counts, nG_imm, nC_imm);
@@ -129,27 +150,39 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     const int raw = active ? (list ? list[kslot] : kslot) : -1;
     const int n = c.n, N = c.N, ld = n + 1;
     if (half == 0 && uslot < nslots) w.agent_of[uslot] = raw;
-    if (active) {
+    if (__ballot(active) == 0ull) return;                // uniform: nothing in this block
+    {
         const double *__restrict__ row = ((raw & CH2_BIT) ? w.xe2 : w.xe) + (size_t)(raw & AGENT_MASK) * n;
-        // eight loads in flight per lane before the first LDS write (one at a time = one memory round trip each)
+        // eight loads in flight per lane before the first LDS write (one at a time = one memory round trip each);
+        // pairs without a request (the last block of a list) keep a row of zeros and walk along: all 64 lanes
+        // stay in the wave for the requests it redoes below
         for (int j0 = half; j0 < n; j0 += 16) {
             double v[8];
 #pragma unroll
-            for (int t = 0; t < 8; t++) v[t] = j0 + 2 * t < n ? row[j0 + 2 * t] : 0.0;
+            for (int t = 0; t < 8; t++) v[t] = active && j0 + 2 * t < n ? row[j0 + 2 * t] : 0.0;
 #pragma unroll
             for (int t = 0; t < 8; t++) if (j0 + 2 * t < n) lds[q * ld + j0 + 2 * t] = v[t];
         }
     }
     __builtin_amdgcn_wave_barrier();                     // one wave per workgroup: LDS is in order
-    if (!active) return;                                 // whole pairs leave together
-    const int a = raw & AGENT_MASK;
+    const int a = active ? raw & AGENT_MASK : 0;
     const size_t St = (size_t)w.St;
     const double *urow = lds + q * ld;
     double x[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = w.x0[(size_t)a * 4 + i];
+    for (int i = 0; i < 4; i++) x[i] = active ? w.x0[(size_t)a * 4 + i] : 0.0;
+    // A stage outside the fast range (kin4_in_range: line-search trial points far outside the box, a few
+    // requests in ten thousand) is not computed here: the pair stops storing, walks on with whatever the
+    // straight-line code makes of it, and the wave redoes the request afterwards over all of its lanes.  (The
+    // thread-per-request code for such a stage, run by the whole wave on the spot, made that wave three times as
+    // long as the others: 1 - 2 % of the waves set the length of every mid-solve launch, profiles/r03_experiments.txt 27.)
+    bool redo = false;
     // lane `half` stores components 2 half and 2 half + 1 of every state
     auto put = [&](int k) {
+#ifdef MPC_DEV_K1A_NOSTORE
+        if (k < N) return;                                   // (timing experiment: only the last state is stored)
+#endif
+        if (!active || redo) return;
         w.trajx[(size_t)(k * 4 + 2 * half) * St + uslot] = half ? x[2] : x[0];
         w.trajx[(size_t)(k * 4 + 2 * half + 1) * St + uslot] = half ? x[3] : x[1];
     };
@@ -158,44 +191,49 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     // two stages at a time, stage k + half by lane `half`, and handed to the partner by DPP
     auto stage = [&](int k, const StageInput<KIN> &u) {
         const double d = urow[2 * k], dl = urow[2 * k + 1];
-        w.useq[(size_t)(2 * k + half) * St + uslot] = half ? dl : d;
-        const bool ok = kin4_in_range(c, u, x);
-        if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
-            // heading / speed at the start of the four RK4 steps, and the stage values of each
-            double ph = x[2], v = x[3];
-            KinRK k0, k1, k2, k3;
-            const double ph0 = ph; kin_rk(c, u, v, k0); kin_next(c, k0, ph, v);
-            const double ph1 = ph; kin_rk(c, u, v, k1); kin_next(c, k1, ph, v);
-            const double ph2 = ph; kin_rk(c, u, v, k2); kin_next(c, k2, ph, v);
-            const double ph3 = ph; kin_rk(c, u, v, k3); kin_next(c, k3, ph, v);
-            // this lane's two increments: steps 2 half and 2 half + 1
-            KinRK ka, kb;
-            ka.v1 = half ? k2.v1 : k0.v1; ka.v2 = half ? k2.v2 : k0.v2; ka.v3 = half ? k2.v3 : k0.v3; ka.v4 = half ? k2.v4 : k0.v4;
-            ka.kp1 = half ? k2.kp1 : k0.kp1; ka.kp2 = half ? k2.kp2 : k0.kp2; ka.kp3 = half ? k2.kp3 : k0.kp3;
-            kb.v1 = half ? k3.v1 : k1.v1; kb.v2 = half ? k3.v2 : k1.v2; kb.v3 = half ? k3.v3 : k1.v3; kb.v4 = half ? k3.v4 : k1.v4;
-            kb.kp1 = half ? k3.kp1 : k1.kp1; kb.kp2 = half ? k3.kp2 : k1.kp2; kb.kp3 = half ? k3.kp3 : k1.kp3;
-            double dxa, dya, dxb, dyb;
-            kin_increment(c, u, half ? ph2 : ph0, ka, true, dxa, dya);
-            kin_increment(c, u, half ? ph3 : ph1, kb, true, dxb, dyb);
-            const double oxa = dpp_xchg<0xB1>(dxa), oya = dpp_xchg<0xB1>(dya);   // the partner's (quad_perm [1,0,3,2])
-            const double oxb = dpp_xchg<0xB1>(dxb), oyb = dpp_xchg<0xB1>(dyb);
-            // the position is lane 0's to keep (it stores x and y, lane 1 heading and speed, which never see
-            // the position): its own increments are steps 0 and 1, its partner's steps 2 and 3 -- lane 1
-            // adds the same operands in an order that means nothing and never uses the result
-            double px = x[0], py = x[1];
-            px = px + dxa; py = py + dya;                                         // step 0
-            px = px + dxb; py = py + dyb;                                         // step 1
-            px = px + oxa; py = py + oya;                                         // step 2
-            px = px + oxb; py = py + oyb;                                         // step 3
-            x[0] = px; x[1] = py; x[2] = ph; x[3] = v;
-        } else {
-            stage_forward<KIN>(c, u, x);                 // some lane is out of range: the thread-per-request code
-        }
+#ifndef MPC_DEV_K1A_NOSTORE
+        if (active) w.useq[(size_t)(2 * k + half) * St + uslot] = half ? dl : d;
+#endif
+        redo = redo || !kin4_in_range(c, u, x);          // (both lanes of a pair hold the same state)
+#ifdef MPC_DEV_K1A_TIMES
+        if (__ballot(redo) != 0ull) stamp.nfall++;
+#endif
+        // heading / speed at the start of the four RK4 steps, and the stage values of each
+        double ph = x[2], v = x[3];
+        KinRK k0, k1, k2, k3;
+        const double ph0 = ph; kin_rk(c, u, v, k0); kin_next(c, k0, ph, v);
+        const double ph1 = ph; kin_rk(c, u, v, k1); kin_next(c, k1, ph, v);
+        const double ph2 = ph; kin_rk(c, u, v, k2); kin_next(c, k2, ph, v);
+        const double ph3 = ph; kin_rk(c, u, v, k3); kin_next(c, k3, ph, v);
+        // this lane's two increments: steps 2 half and 2 half + 1
+        KinRK ka, kb;
+        ka.v1 = half ? k2.v1 : k0.v1; ka.v2 = half ? k2.v2 : k0.v2; ka.v3 = half ? k2.v3 : k0.v3; ka.v4 = half ? k2.v4 : k0.v4;
+        ka.kp1 = half ? k2.kp1 : k0.kp1; ka.kp2 = half ? k2.kp2 : k0.kp2; ka.kp3 = half ? k2.kp3 : k0.kp3;
+        kb.v1 = half ? k3.v1 : k1.v1; kb.v2 = half ? k3.v2 : k1.v2; kb.v3 = half ? k3.v3 : k1.v3; kb.v4 = half ? k3.v4 : k1.v4;
+        kb.kp1 = half ? k3.kp1 : k1.kp1; kb.kp2 = half ? k3.kp2 : k1.kp2; kb.kp3 = half ? k3.kp3 : k1.kp3;
+        double dxa, dya, dxb, dyb;
+        kin_increment(c, u, half ? ph2 : ph0, ka, !redo, dxa, dya);
+        kin_increment(c, u, half ? ph3 : ph1, kb, !redo, dxb, dyb);
+        const double oxa = dpp_xchg<0xB1>(dxa), oya = dpp_xchg<0xB1>(dya);   // the partner's (quad_perm [1,0,3,2])
+        const double oxb = dpp_xchg<0xB1>(dxb), oyb = dpp_xchg<0xB1>(dyb);
+        // the position is lane 0's to keep (it stores x and y, lane 1 heading and speed, which never see
+        // the position): its own increments are steps 0 and 1, its partner's steps 2 and 3 -- lane 1
+        // adds the same operands in an order that means nothing and never uses the result
+        double px = x[0], py = x[1];
+        px = px + dxa; py = py + dya;                                         // step 0
+        px = px + dxb; py = py + dyb;                                         // step 1
+        px = px + oxa; py = py + oya;                                         // step 2
+        px = px + oxb; py = py + oyb;                                         // step 3
+        x[0] = px; x[1] = py; x[2] = ph; x[3] = v;
         put(k + 1);
     };
     for (int k = 0; k < N; k += 2) {
         const int km = min(k + half, N - 1);
         StageInput<KIN> um, up;
+#ifdef MPC_DEV_K1A_TIMES
+        if (__ballot(!(fabs(urow[2 * km + 1]) <= 0.75)) != 0ull) stamp.nmid++;
+        if (__ballot(!(fabs(urow[2 * km + 1]) < 1.0e5)) != 0ull) stamp.nslow++;
+#endif
         prep_input(c, urow[2 * km], urow[2 * km + 1], um);
         up.ad = dpp_xchg<0xB1>(um.ad); up.beta = dpp_xchg<0xB1>(um.beta);
         up.sb_lr = dpp_xchg<0xB1>(um.sb_lr); up.cb_lr = dpp_xchg<0xB1>(um.cb_lr);
@@ -209,6 +247,23 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
         ub.mk0 = half ? um.mk0 : up.mk0; ub.mk1 = half ? um.mk1 : up.mk1;
         stage(k, ua);
         if (k + 1 < N) stage(k + 1, ub);
+    }
+    // the requests that met a stage outside the fast range, one after the other over the whole wave: per stage
+    // the same choice between the two forms of the RK4 step, and the same bits, as every other K1a kernel
+    unsigned long long todo = __ballot(redo && active && half == 0);
+    while (todo != 0ull) {                               // uniform
+        const int l0 = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int aq = __builtin_amdgcn_readlane(raw, l0) & AGENT_MASK;
+        const int uq = blockIdx.x * RPB + (l0 >> 1);
+        const double *uro = lds + (l0 >> 1) * ld;
+        const bool stage_lane = lane < N;
+        const double dq = stage_lane ? uro[2 * lane] : 0.0, dlq = stage_lane ? uro[2 * lane + 1] : 0.0;
+        double xq[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xq[i] = w.x0[(size_t)aq * 4 + i];
+        double *const tj = w.trajx + uq;
+        kin_wide_rollout(c, xq, dq, dlq, lane, [=](int k, int i, double v) { tj[(size_t)(k * 4 + i) * St] = v; });
     }
 }
 
@@ -281,10 +336,9 @@ rollout_quad_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 // The body of the wave-per-request rollout, shared by rollout_wide_kernel (states to the slot-indexed
 // scratch) and the persistent solo kernel (states to the wave's LDS): `put(k, i, v)` stores component
 // i of the state at the end of stage k - 1 (k = 0: the initial state).  d / dl are the inputs of
-// stage `lane` (lanes >= N: zeros); `row` is the control row (fallback path only).
+// stage `lane` (lanes >= N: zeros).  All 64 lanes must be active.
 template <class Put>
-__device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double *__restrict__ row,
-                                                 const double (&x0)[4], double d, double dl, int lane, Put put)
+__device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double (&x0)[4], double d, double dl, int lane, Put put)
 {
     const int N = c.N;
     const bool stage_lane = lane < N;
@@ -295,42 +349,33 @@ __device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double *
         for (int i = 0; i < 4; i++) put(0, i, x0[i]);
     }
     // ---- phase A: heading and speed along the horizon (uniform, serial); lane s & 63 keeps the
-    // (heading, speed) at the start of RK4 step s, lane k the state at the end of stage k
+    // (heading, speed) at the start of RK4 step s, lane k the state at the end of stage k.  A stage outside
+    // the fast range (kin4_in_range: a trial point of the line search far outside the box, as a rule) runs
+    // the same recursion with the roundings of stage_forward_steps -- what the thread-per-request kernel
+    // computes for it -- and its steps are marked (gen) for phase B.
     double ph = x0[2], v = x0[3];
     constexpr int PASS = 4;
     double cph[PASS] = {0.0, 0.0, 0.0, 0.0}, cv[PASS] = {0.0, 0.0, 0.0, 0.0}, eph = 0.0, ev = 0.0;
-    bool allok = true;
+    int gen = 0;                                         // bit p: this lane's step of pass p belongs to such a stage
+    bool anygen = false;                                 // uniform
     for (int k = 0; k < N; k++) {
         StageInput<KIN> uk;
         uk.ad = rdlane(u.ad, k); uk.beta = rdlane(u.beta, k); uk.sb_lr = rdlane(u.sb_lr, k);
         const double xs[4] = {0.0, 0.0, ph, v};
-        allok = allok && kin4_in_range(c, uk, xs);
+        const bool inr = __ballot(!kin4_in_range(c, uk, xs)) == 0ull;   // (every lane holds the same values)
+        anygen = anygen || !inr;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int s = 4 * k + j;
             if (lane == (s & 63)) {
 #pragma unroll
-                for (int p = 0; p < PASS; p++) if ((s >> 6) == p) { cph[p] = ph; cv[p] = v; }
+                for (int p = 0; p < PASS; p++) if ((s >> 6) == p) { cph[p] = ph; cv[p] = v; gen |= inr ? 0 : 1 << p; }
             }
             KinRK kr;
-            kin_rk(c, uk, v, kr);
-            kin_next(c, kr, ph, v);
+            if (inr) { kin_rk(c, uk, v, kr); kin_next(c, kr, ph, v); }
+            else { kin_gen_rk(c, uk, v, kr); kin_gen_next(c, kr, ph, v); }
         }
         if (lane == k) { eph = ph; ev = v; }
-    }
-    if (!allok) {
-        // an out-of-range stage somewhere: this request follows the thread-per-agent code, on one lane
-        if (lane == 0) {
-            double x[4] = {x0[0], x0[1], x0[2], x0[3]};
-            for (int k = 0; k < N; k++) {
-                StageInput<KIN> uk;
-                prep_input(c, row[2 * k], row[2 * k + 1], uk);
-                stage_forward<KIN>(c, uk, x);
-#pragma unroll
-                for (int i = 0; i < 4; i++) put(k + 1, i, x[i]);
-            }
-        }
-        return;
     }
     // ---- phase B: position increment of RK4 step s = lane (and lane + 64)
     double dx[PASS] = {0.0, 0.0, 0.0, 0.0}, dy[PASS] = {0.0, 0.0, 0.0, 0.0};
@@ -341,9 +386,16 @@ __device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double *
         const int k = (s >> 2) < N ? (s >> 2) : N - 1;   // lanes past the horizon compute a copy, unused
         StageInput<KIN> uk;
         uk.ad = __shfl(u.ad, k); uk.beta = __shfl(u.beta, k); uk.sb_lr = __shfl(u.sb_lr, k);
+        const bool g = ((gen >> p) & 1) != 0 && (s >> 2) < N;
         KinRK kr;
         kin_rk(c, uk, cv[p], kr);
-        kin_increment(c, uk, cph[p], kr, true, dx[p], dy[p]);
+        kin_increment(c, uk, cph[p], kr, !g, dx[p], dy[p]);
+        if (anygen) {                                    // uniform; rare
+            double gx, gy;
+            kin_gen_rk(c, uk, g ? cv[p] : 0.0, kr);
+            kin_gen_increment(c, uk, g ? cph[p] : 0.0, g ? cv[p] : 0.0, kr, gx, gy);
+            dx[p] = g ? gx : dx[p]; dy[p] = g ? gy : dy[p];
+        }
     }
     // ---- phase C: positions, summed in step order; lane k keeps the position at the end of stage k
     double px = x0[0], py = x0[1], epx = 0.0, epy = 0.0;
@@ -392,7 +444,7 @@ rollout_wide_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 #pragma unroll
     for (int i = 0; i < 4; i++) x0[i] = w.x0[(size_t)a * 4 + i];
     double *const tj = w.trajx + uslot;
-    kin_wide_rollout(c, row, x0, d, dl, lane,
+    kin_wide_rollout(c, x0, d, dl, lane,
                      [=](int k, int i, double v) { tj[(size_t)(k * 4 + i) * St] = v; });
 }
 

@@ -63,7 +63,7 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
 #pragma unroll
     for (int i = 0; i < NX; i++) x0[i] = w.x0[(size_t)a * NX + i];
     if constexpr (MODEL == KIN) {
-        if (wide) kin_wide_rollout(c, row, x0, d, dl, lane, [=](int k, int i, double v) { tj[k * 4 + i] = v; });
+        if (wide) kin_wide_rollout(c, x0, d, dl, lane, [=](int k, int i, double v) { tj[k * 4 + i] = v; });
     }
     if constexpr (MODEL == PAC) {
         if (hl < 4 && live) {                              // the serial recurrence on a quad of lanes (rhs_quad)

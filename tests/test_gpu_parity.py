@@ -848,6 +848,61 @@ def test_quad_rollout_is_bit_identical(dev, monkeypatch, model, N):
     assert fin.float().mean() >= 0.9 and (stq[:, 0] == 1).float().mean() >= (0.8 if N <= 20 else 0.3)
 
 
+@pytest.mark.parametrize("N", [20, 40, 9])
+def test_stages_outside_the_fast_range_are_the_same_in_every_rollout(dev, O, monkeypatch, N):
+    """A line-search trial point far outside the box (steering of a radian or more at speed) makes the heading
+    turn by more than the rotation kernels hold in one RK4 step: such a STAGE takes the plain RK4 form, the
+    others of the same request the straight-line one.  The two-lanes-per-request kernel hands such a request to
+    its whole wave afterwards, the wave-per-request kernel (and the persistent kernel's evaluation) serves the
+    stage in its lanes: all of them must give the bits of the thread-per-request kernel, and the oracle's cost
+    and gradient within 1e-12 / 1e-9."""
+    B = 777
+    rng = np.random.default_rng(41)
+    x0 = synthetic_states(0, B, seed=29)
+    x0[:, 3] = rng.uniform(0.3, 6.0, B)                           # speeds up to where a full lock spins the car
+    U = np.tile([0.6, 0.0], (B, N)) + rng.uniform(-.4, .4, (B, 2 * N)) * np.tile([1, .6], N)
+    wild = rng.random((B, N)) < 0.08                              # a few stages per request, some requests none
+    wild[::7] = False
+    wild[3::50] = True                                            # ... and some all of them
+    U[:, 1::2] = np.where(wild, np.sign(rng.standard_normal((B, N))) * rng.uniform(1.3, 1.85, (B, N)), U[:, 1::2])  # wheels near 90 degrees
+    U[5::90, 1] = 2.0e5                                           # beyond the lean range as well: the library route
+    X0, cl_np = T(x0, dev), straight_centerline()
+    cl, Ut = T(cl_np, dev), T(U, dev)
+    cfg = mp.default_config(0, N)
+    monkeypatch.setenv("MPC_WIDE_MAX", "-1")
+    e2 = mp.BatchedMPC(cfg, dev)                                  # two lanes per request
+    p2, g2, _ = e2.eval_cost_grad(X0, cl, Ut)
+    monkeypatch.setenv("MPC_NO_QUAD", "1")
+    e1 = mp.BatchedMPC(cfg, dev)                                  # one thread per request
+    p1, g1, _ = e1.eval_cost_grad(X0, cl, Ut)
+    monkeypatch.delenv("MPC_NO_QUAD")
+    pw, gw, _ = e2.eval_cost_grad(X0, cl, Ut, wave=True)          # one wave per request (the persistent kernel's)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1.25), torch.nan_to_num(b, nan=1.25))
+    assert same(p2, p1) and same(g2, g1)
+    assert same(pw, p1) and same(gw, g1)
+    # the requests do meet such stages (the test would be empty otherwise): kin4_in_range (mpc_device.hpp) of the
+    # first stage, whose state is known, restated here
+    lf, lr, h = cfg.veh[1], cfg.veh[2], cfg.Ts / cfg.nfe
+    beta = np.arctan2(lf * np.tan(U[:, 1]), lf + lr)
+    vmax = np.abs(x0[:, 3]) + 2.0 * cfg.Ts * (np.abs(cfg.accel * U[:, 0]) + np.abs(cfg.friction * x0[:, 3]))
+    out0 = h * vmax * np.abs(np.sin(beta) / lr) > 0.7
+    assert 0.02 < out0.mean() < 0.5 and (wild.sum(1) > 0).mean() > 0.3, out0.mean()
+    po, go = O.psi_batch(O.default_config(0, N), x0, cl_np, U)
+    fin = np.isfinite(po)
+    assert fin.mean() > 0.95
+    pn, gn = p2.cpu().numpy(), g2.cpu().numpy()
+    assert np.allclose(pn[fin], po[fin], rtol=1e-12, atol=0)
+    assert np.abs(gn[fin] - go[fin]).max() <= 1e-9 * np.abs(go[fin]).max()
+    # and inside a solve, through the work lists: rounds with the two-lane kernel against thread-per-request rounds
+    monkeypatch.setenv("MPC_SOLO_MAX", "0")
+    Bs = 300
+    cs = mp.default_config(0, N, max_total_inner=120)
+    Ua, _, sa = mp.BatchedMPC(cs, dev).solve(X0[:Bs], cl, Ut[:Bs].clone())
+    monkeypatch.setenv("MPC_NO_QUAD", "1")
+    Ub, _, sb = mp.BatchedMPC(cs, dev).solve(X0[:Bs], cl, Ut[:Bs].clone())
+    assert same(Ua, Ub) and same(sa, sb)
+
+
 @pytest.mark.parametrize("model,N,B,kw", [
     (0, 20, 700, {}), (1, 12, 300, {}), (0, 40, 150, {}), (0, 32, 100, dict(lbfgs_memory=25)),
     (1, 10, 96, dict(constr_mode=1, D_lb=[-np.inf] * 6, D_ub=[0.0] * 6, g_off=[20, 1, 1, 0.5, 1, 0.1], Sigma0=10.0)),
