@@ -1337,10 +1337,10 @@ extern "C" int mpc_set_profile(mpc_handle *h, int on)
     return MPC_OK;
 }
 
-#ifdef MPC_DEV_K1A_TIMES
-extern "C" int mpc_dev_k1a_times(long long *host_out)    // (timing experiment) the stamps of the last K1a launch
+#ifdef MPC_DEV_STAMP
+extern "C" int mpc_dev_stamps(long long *host_out)       // (timing experiment) the stamps of the last launch of the kernel chosen
 {
     (void)hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mpc::g_k1a_times), sizeof(long long) * 4 * 16384) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mpc::g_dev_stamps), sizeof(long long) * 4 * mpc::DEV_STAMPS) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -530,17 +530,50 @@ MPC_DEV void rk4_step_pac(const DevCfg &c, double (&x)[6], F f)
     for (int i = 0; i < 6; i++) x[i] = fma(h6, ((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i], x[i]);
 }
 
-// one stage x <- f_d(x, u) : nfe RK4 steps
-MPC_DEV void stage_forward_steps(const DevCfg &c, const StageInput<PAC> &u, double (&x)[6])
+// A trial point of the line search can make the Pacejka model blow up inside the horizon (RK4 at this step size is
+// only stable near the road): heading, velocities and yaw rate all NaN.  Every derivative of such a state is NaN
+// (each of the six reads at least one of the four), so the state stays where it is for the rest of the horizon --
+// but every one of its 16 evaluations per stage would drag its whole wave through the library route of the range
+// tests in rhs / rhs_quad (mid-solve: 3 % of the rollout waves, five times as long as the others, set the length of
+// every launch).  A stage that STARTS there is therefore not evaluated: the lanes walk a harmless state instead and
+// get their NaNs back afterwards.
+MPC_DEV bool pac_state_is_lost(const double (&x)[6]) { return x[2] != x[2] && x[3] != x[3] && x[4] != x[4] && x[5] != x[5]; }
+// ... and so is a stage whose steering input is NaN or infinite, or whose drive is NaN (the trial point itself was
+// formed from a NaN direction): sin / cos of the steering, or the drivetrain force, put a NaN into all three
+// accelerations at once, the heading follows the yaw rate within the RK4 step, the position the velocities
+MPC_DEV bool pac_stage_is_lost(const StageInput<PAC> &u, const double (&x)[6])
 {
+    return pac_state_is_lost(x) || !(fabs(u.dl) < INFINITY) || u.d != u.d;
+}
+MPC_DEV void pac_park(StageInput<PAC> &u, double (&x)[6])
+{
+    x[2] = 0.0; x[3] = 1.0; x[4] = 0.0; x[5] = 0.0;
+    u.d = 0.0; u.dl = 0.0; u.sd = 0.0; u.cd = 1.0;
+}
+MPC_DEV void pac_lose(double (&x)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = __builtin_nan("");
+}
+// one stage x <- f_d(x, u) : nfe RK4 steps
+MPC_DEV void stage_forward_steps(const DevCfg &c, const StageInput<PAC> &u_in, double (&x)[6])
+{
+    StageInput<PAC> u = u_in;
+    const bool lost = pac_stage_is_lost(u, x);
+    if (lost) pac_park(u, x);
     for (int s = 0; s < c.nfe; s++)
         rk4_step_pac(c, x, [&](const double (&y)[6], double (&k)[6]) { Lin<PAC> dummy; rhs<false>(c, u, y, k, dummy); });
+    if (lost) pac_lose(x);
 }
 // the same by a quad of lanes holding identical (x, u); role = lane & 3 (see rhs_quad)
-MPC_DEV void stage_forward_quad(const DevCfg &c, const StageInput<PAC> &u, double (&x)[6], int role)
+MPC_DEV void stage_forward_quad(const DevCfg &c, const StageInput<PAC> &u_in, double (&x)[6], int role)
 {
+    StageInput<PAC> u = u_in;
+    const bool lost = pac_stage_is_lost(u, x);
+    if (lost) pac_park(u, x);
     for (int s = 0; s < c.nfe; s++)
         rk4_step_pac(c, x, [&](const double (&y)[6], double (&k)[6]) { rhs_quad(c, u, y, k, role); });
+    if (lost) pac_lose(x);
 }
 MPC_DEV void stage_forward_steps(const DevCfg &c, const StageInput<KIN> &u, double (&x)[4])
 {

@@ -113,29 +113,13 @@ rollout_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
 #endif
 template <class Put>
 __device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double (&x0)[4], double d, double dl, int lane, Put put);
-#ifdef MPC_DEV_K1A_TIMES
-__device__ long long g_k1a_times[4 * 16384];             // (timing experiment) per workgroup: start, end (100 MHz clock), HW_ID, XCC_ID
-struct K1aStamp {
-    long long t0; int blk; int nfall = 0, nmid = 0, nslow = 0;
-    __device__ K1aStamp(int b) : t0(__builtin_amdgcn_s_memrealtime()), blk(b) {}
-    __device__ ~K1aStamp()
-    {
-        if (threadIdx.x == 0 && blk < 16384) {
-            g_k1a_times[4 * blk] = t0; g_k1a_times[4 * blk + 1] = __builtin_amdgcn_s_memrealtime();
-            g_k1a_times[4 * blk + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-            g_k1a_times[4 * blk + 3] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15)  // XCC_ID
-                                       | ((long long)nfall << 8) | ((long long)nmid << 16) | ((long long)nslow << 24);
-        }
-    }
-};
-#endif
 __global__ void __launch_bounds__(64, MPC_K1A_WAVES)
 rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ lists,
                     const int *__restrict__ counts, int nG_imm, int nC_imm)
 {
 #pragma clang fp contract(off)
-#ifdef MPC_DEV_K1A_TIMES
-    K1aStamp stamp(blockIdx.x);
+#if MPC_DEV_STAMP == 1
+    DevStamp stamp(blockIdx.x);
 #endif
     constexpr int RPB = 32;                              // requests per block
     extern __shared__ double lds[];                      // [RPB][n + 1] control rows
@@ -195,7 +179,7 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
         if (active) w.useq[(size_t)(2 * k + half) * St + uslot] = half ? dl : d;
 #endif
         redo = redo || !kin4_in_range(c, u, x);          // (both lanes of a pair hold the same state)
-#ifdef MPC_DEV_K1A_TIMES
+#if MPC_DEV_STAMP == 1
         if (__ballot(redo) != 0ull) stamp.nfall++;
 #endif
         // heading / speed at the start of the four RK4 steps, and the stage values of each
@@ -230,7 +214,7 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     for (int k = 0; k < N; k += 2) {
         const int km = min(k + half, N - 1);
         StageInput<KIN> um, up;
-#ifdef MPC_DEV_K1A_TIMES
+#if MPC_DEV_STAMP == 1
         if (__ballot(!(fabs(urow[2 * km + 1]) <= 0.75)) != 0ull) stamp.nmid++;
         if (__ballot(!(fabs(urow[2 * km + 1]) < 1.0e5)) != 0ull) stamp.nslow++;
 #endif
@@ -279,6 +263,9 @@ rollout_quad_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
 {
     constexpr int NX = 6, RPB = 16;                      // requests per block
     extern __shared__ double lds[];                      // [RPB][n + 1] control rows
+#if MPC_DEV_STAMP == 4
+    DevStamp stamp(blockIdx.x);
+#endif
     const SlotMap sm(counts, nG_imm, nC_imm);
     const int lane = threadIdx.x, q = lane >> 2, role = lane & 3;
     const int uslot = blockIdx.x * RPB + q;
@@ -321,6 +308,17 @@ rollout_quad_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
         if (role == 1) w.useq[(size_t)(2 * k + 1) * St + uslot] = dl;
         StageInput<PAC> u;
         prep_input(c, d, dl, u);
+#if MPC_DEV_STAMP == 4
+        {   // stages that START from a state with a non-finite component / from a finite one outside the fast ranges
+            bool fin = true;
+#pragma unroll
+            for (int i = 0; i < NX; i++) fin = fin && fabs(x[i]) < 1.0e300;
+            const bool inr = fabs(x[2]) < 1.0e5 && fabs(dl) < 1.0e5 && (x[3] != 0.0 || (x[5] * c.lf + x[4] != 0.0 && x[5] * c.lr - x[4] != 0.0));
+            if (__ballot(!fin) != 0ull) stamp.nfall++;
+            if (__ballot(fin && !inr) != 0ull) stamp.nmid++;
+            if (__ballot(!fin) != 0ull && k == 0) stamp.nslow++;
+        }
+#endif
         stage_forward_quad(c, u, x, role);
         put(k + 1);
     }
@@ -529,6 +527,24 @@ __device__ __forceinline__ void stage_sens_record(const DevCfg &c, const double 
     StageInput<MODEL> u;
     prep_input(c, d, dl, u);
     double T[NX][NX];
+    if constexpr (MODEL == PAC) {
+        // a stage that starts from a lost state or input (pac_stage_is_lost: the rollout blew up earlier in the horizon): every
+        // partial derivative there is NaN and so is every sensitivity that is computed at all; the lanes walk a
+        // harmless state instead of dragging their wave through the library route 16 times, and store the NaNs
+        const bool lost = pac_stage_is_lost(u, xs);
+        double xp[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) xp[i] = xs[i];
+        if (lost) pac_park(u, xp);
+        stage_tangents_at<MODEL>(c, u, xp, xe, T);
+#pragma unroll
+        for (int dd = 0; dd < NX; dd++) {
+#pragma unroll
+            for (int i = 0; i < NX; i++)
+                if (!sens_is_const<MODEL>(dd, i)) put(NX + 2 + dd * NX + i, lost ? __builtin_nan("") : T[dd][i]);
+        }
+        return;
+    }
     stage_tangents_at<MODEL>(c, u, xs, xe, T);
 #pragma unroll
     for (int dd = 0; dd < NX; dd++) {
@@ -708,6 +724,9 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
 {
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE, BLK = FusedBlk<MODEL>::BLK;
     extern __shared__ double s_rec[];                    // [JS + 1][N][SPB]; row JS = stage cost
+#if MPC_DEV_STAMP == 2
+    DevStamp stamp(blockIdx.x * (BLK / 64) + (threadIdx.x >> 6));
+#endif
     const SlotMap sm(counts, nG_imm, nC_imm);
     const int N = c.N, SPB = BLK / N;
     const int slot0 = blockIdx.x * SPB, nslots = sm.nblk * 64;

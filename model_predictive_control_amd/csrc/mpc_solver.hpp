@@ -94,6 +94,26 @@ struct Workspace {
     int Ls;                                        // stride between the two work lists
 };
 
+#ifdef MPC_DEV_STAMP
+// (timing experiments, never in the product build: -DMPC_DEV_STAMP=1 K1a (two lanes per request), 2 the fused K1b+K1c kernel,
+// 3 the step kernel, 4 K1a of the Pacejka model (four lanes per request))
+// per wave of the last launch: start, end (100 MHz clock), HW_ID, XCC_ID | counters
+constexpr int DEV_STAMPS = 65536;
+__device__ long long g_dev_stamps[4 * DEV_STAMPS];
+struct DevStamp {
+    long long t0; int idx; int nfall = 0, nmid = 0, nslow = 0;
+    __device__ DevStamp(int i) : t0(__builtin_amdgcn_s_memrealtime()), idx(i) {}
+    __device__ ~DevStamp()
+    {
+        if ((threadIdx.x & 63) == 0 && idx < DEV_STAMPS) {
+            g_dev_stamps[4 * idx] = t0; g_dev_stamps[4 * idx + 1] = __builtin_amdgcn_s_memrealtime();
+            g_dev_stamps[4 * idx + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+            g_dev_stamps[4 * idx + 3] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15)  // XCC_ID
+                                        | ((long long)nfall << 8) | ((long long)nmid << 16) | ((long long)nslow << 24);
+        }
+    }
+};
+#endif
 // ------------------------------------------------------------------ wavefront helpers
 __device__ __forceinline__ double rdlane(double v, int l)
 {
@@ -1251,6 +1271,9 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
     __shared__ int s_next;
     extern __shared__ double s_hist[];                   // MC < 0: 2 M n doubles per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#if MPC_DEV_STAMP == 3
+    DevStamp stamp(blockIdx.x * STEP_WAVES + wv);
+#endif
     double *hist = s_hist + (MC < 0 ? (size_t)wv * 2 * P * c.n : 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) { counts_next[0] = 0; counts_next[1] = 0; } // next round's buffer
     // Which of the workgroup's agents are still running: one coalesced look at their phase words.
@@ -1304,6 +1327,10 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
                 hist_ready = true;
             }
         }
+#if MPC_DEV_STAMP == 3
+        stamp.nfall++;                                   // agent-steps of this wave
+        if (hist_ready) stamp.nmid++;
+#endif
         const int req = advance_agent<NE, MC, HASM>(c, w, a, lane, cur, hist, hist_ready, true, /*allow_chain=*/true, P);
         if (lane == 0) s_req[loc] = req;
         loc = loc_next;
