@@ -903,6 +903,60 @@ def test_stages_outside_the_fast_range_are_the_same_in_every_rollout(dev, O, mon
     assert same(Ua, Ub) and same(sa, sb)
 
 
+def test_lost_pacejka_stages_give_what_the_oracle_computes(dev, O, monkeypatch):
+    """A trial point on which the Pacejka model blows up inside the horizon (or whose inputs are NaN / infinite)
+    leaves heading, velocities and yaw rate NaN; every later stage of it is NaN whatever is computed, and the
+    rollout and sensitivity kernels do not evaluate such a stage (pac_stage_is_lost: their waves would walk the
+    library route of every range test).  The oracle has no such shortcut: the trajectories must be NaN exactly
+    where its are and equal elsewhere, cost and gradient likewise -- from the four-lane rollout, the
+    thread-per-request one and the wave-per-agent evaluation of the persistent kernel."""
+    N, B = 12, 260
+    rng = np.random.default_rng(77)
+    x0 = synthetic_states(1, B, seed=31)
+    U = np.tile([0.6, 0.0], (B, N)) + rng.uniform(-.4, .4, (B, 2 * N)) * np.tile([1, .3], N)
+    k_bad = rng.integers(0, N, B)
+    kind = np.arange(B) % 8                                       # 0, 1: untouched
+    for a in range(B):
+        k = k_bad[a]
+        if kind[a] == 2: U[a, 2 * k + 1] = np.nan                 # steering NaN at one stage
+        if kind[a] == 3: U[a, 2 * k + 1] = np.inf
+        if kind[a] == 4: U[a, 2 * k] = np.nan                     # drive NaN
+        if kind[a] == 5: U[a, 2 * k:] = np.nan                    # everything from a stage on (a NaN direction)
+        if kind[a] == 6: U[a, 2 * k] = 1.0e6 * (1 if a % 16 < 8 else -1)   # the model blows up by itself
+        if kind[a] == 7: U[a, 2 * k] = 3.0e3; U[a, 2 * k + 1] = 2.5
+    cl_np = straight_centerline()
+    X0, cl, Ut = T(x0, dev), T(cl_np, dev), T(U, dev)
+    cfg, ocfg = mp.default_config(1, N), O.default_config(1, N)
+    eng = mp.BatchedMPC(cfg, dev)
+    Xg = eng.rollout(X0, Ut).cpu().numpy()
+    Xo = np.stack([O.rollout(ocfg, x0[a], U[a]) for a in range(B)])
+    nan_g, nan_o = np.isnan(Xg), np.isnan(Xo)
+    assert (nan_g == nan_o).all()
+    assert nan_o[kind >= 2].any(1).any(1).mean() > 0.9 and not nan_o[kind < 2].any()   # the cases are what they claim
+    both = ~nan_o
+    assert np.array_equal(np.isinf(Xg), np.isinf(Xo))
+    fin = both & np.isfinite(Xo)
+    assert np.abs(Xg[fin] - Xo[fin]).max() <= 1e-9 * max(1.0, np.abs(Xo[fin]).max())
+    po, go = O.psi_batch(ocfg, x0, cl_np, U)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1.25), torch.nan_to_num(b, nan=1.25))
+    monkeypatch.setenv("MPC_WIDE_MAX", "-1")
+    outs = []
+    for env in ({}, {"MPC_NO_QUAD": "1"}, {"MPC_UNFUSED_EVAL": "1"}):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        e = mp.BatchedMPC(cfg, dev)
+        outs.append(e.eval_cost_grad(X0, cl, Ut)[:2])
+        for k in env: monkeypatch.delenv(k)
+    outs.append(eng.eval_cost_grad(X0, cl, Ut, wave=True)[:2])
+    for p, g in outs[1:]:
+        assert same(p, outs[0][0]) and same(g, outs[0][1])
+    pg, gg = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy()
+    assert np.array_equal(np.isnan(pg), np.isnan(po)) and np.array_equal(np.isnan(gg), np.isnan(go))
+    ok = np.isfinite(po)
+    assert 0.2 < ok.mean() < 0.6
+    assert np.allclose(pg[ok], po[ok], rtol=1e-12, atol=0)
+    assert np.abs(gg[ok] - go[ok]).max() <= 1e-9 * np.abs(go[ok]).max()
+
+
 @pytest.mark.parametrize("model,N,B,kw", [
     (0, 20, 700, {}), (1, 12, 300, {}), (0, 40, 150, {}), (0, 32, 100, dict(lbfgs_memory=25)),
     (1, 10, 96, dict(constr_mode=1, D_lb=[-np.inf] * 6, D_ub=[0.0] * 6, g_off=[20, 1, 1, 0.5, 1, 0.1], Sigma0=10.0)),
