@@ -160,12 +160,25 @@ solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= total) break;
         const int a = list ? list[i] : i;
+#if MPC_DEV_STAMP == 5
+        const long long st0 = __builtin_amdgcn_s_memrealtime();
+        long long ntrip = 0;
+#endif
         for (long long trip = 0; trip < max_trips; trip++) {
             const AgentIn<NE> in = load_agent<NE>(c, w, a, lane);
             const int req = advance_agent<NE, MC>(c, w, a, lane, in, hist, false, /*allow_spec=*/spec);
             if ((req & (REQ_GRAD | REQ_COST)) == 0) break;              // uniform: the agent is done
             solo_eval<MODEL>(c, w, a, lane, req, traj, rec);
+#if MPC_DEV_STAMP == 5
+            ntrip++;
+#endif
         }
+#if MPC_DEV_STAMP == 5
+        if (lane == 0 && i < DEV_STAMPS) {   // (one buffer for all groups: the claim index of the group whose kernel ran last wins)
+            g_dev_stamps[4 * i] = st0; g_dev_stamps[4 * i + 1] = __builtin_amdgcn_s_memrealtime();
+            g_dev_stamps[4 * i + 2] = ntrip; g_dev_stamps[4 * i + 3] = a;
+        }
+#endif
     }
 }
 
