@@ -356,24 +356,24 @@ __device__ __forceinline__ void kin_wide_rollout(const DevCfg &c, const double (
     double cph[PASS] = {0.0, 0.0, 0.0, 0.0}, cv[PASS] = {0.0, 0.0, 0.0, 0.0}, eph = 0.0, ev = 0.0;
     int gen = 0;                                         // bit p: this lane's step of pass p belongs to such a stage
     bool anygen = false;                                 // uniform
-    for (int k = 0; k < N; k++) {
-        StageInput<KIN> uk;
-        uk.ad = rdlane(u.ad, k); uk.beta = rdlane(u.beta, k); uk.sb_lr = rdlane(u.sb_lr, k);
-        const double xs[4] = {0.0, 0.0, ph, v};
-        const bool inr = __ballot(!kin4_in_range(c, uk, xs)) == 0ull;   // (every lane holds the same values)
-        anygen = anygen || !inr;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int s = 4 * k + j;
-            if (lane == (s & 63)) {
+    for (int p = 0; p < PASS; p++) {                     // pass p: stages 16 p .. 16 p + 15 = RK4 steps 64 p .. 64 p + 63
+        const int k1 = N < 16 * (p + 1) ? N : 16 * (p + 1);
+        for (int k = 16 * p; k < k1; k++) {
+            StageInput<KIN> uk;
+            uk.ad = rdlane(u.ad, k); uk.beta = rdlane(u.beta, k); uk.sb_lr = rdlane(u.sb_lr, k);
+            const double xs[4] = {0.0, 0.0, ph, v};
+            const bool inr = __ballot(!kin4_in_range(c, uk, xs)) == 0ull;   // (every lane holds the same values)
+            anygen = anygen || !inr;
 #pragma unroll
-                for (int p = 0; p < PASS; p++) if ((s >> 6) == p) { cph[p] = ph; cv[p] = v; gen |= inr ? 0 : 1 << p; }
+            for (int j = 0; j < 4; j++) {
+                if (lane == ((4 * k + j) & 63)) { cph[p] = ph; cv[p] = v; gen |= inr ? 0 : 1 << p; }
+                KinRK kr;
+                if (inr) { kin_rk(c, uk, v, kr); kin_next(c, kr, ph, v); }
+                else { kin_gen_rk(c, uk, v, kr); kin_gen_next(c, kr, ph, v); }
             }
-            KinRK kr;
-            if (inr) { kin_rk(c, uk, v, kr); kin_next(c, kr, ph, v); }
-            else { kin_gen_rk(c, uk, v, kr); kin_gen_next(c, kr, ph, v); }
+            if (lane == k) { eph = ph; ev = v; }
         }
-        if (lane == k) { eph = ph; ev = v; }
     }
     // ---- phase B: position increment of RK4 step s = lane (and lane + 64)
     double dx[PASS] = {0.0, 0.0, 0.0, 0.0}, dy[PASS] = {0.0, 0.0, 0.0, 0.0};

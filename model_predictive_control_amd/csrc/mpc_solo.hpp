@@ -43,10 +43,21 @@ template <int MODEL> __host__ __device__ inline size_t solo_lds_doubles(int nfe,
 }
 
 // the evaluation(s) agent `a` asked for (req: REQ_GRAD or REQ_COST, plus REQ_SPEC) by its whole wave
+#if MPC_DEV_STAMP == 5
+struct SoloClk { long long roll = 0, recs = 0, adj = 0; };
+#define SOLO_CLK_ARG , SoloClk &clk
+#define SOLO_CLK(field, t) do { const long long now_ = __builtin_amdgcn_s_memrealtime(); clk.field += now_ - t; t = now_; } while (0)
+#else
+#define SOLO_CLK_ARG
+#define SOLO_CLK(field, t) do { } while (0)
+#endif
 template <int MODEL>
 __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, int a, int lane, int req,
-                                          double *traj, double *rec)
+                                          double *traj, double *rec SOLO_CLK_ARG)
 {
+#if MPC_DEV_STAMP == 5
+    long long tclk = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
     const int N = c.N, n = c.n;
     const bool wide = solo_wide(MODEL, c.nfe), dual = solo_dual(MODEL, c.nfe, N);   // uniform
@@ -93,6 +104,7 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
         }
     }
     __builtin_amdgcn_wave_barrier();                       // LDS is in order within a wave
+    SOLO_CLK(roll, tclk);
     if (stage_lane) {
         double xs[NX], xe[NX];
 #pragma unroll
@@ -106,7 +118,9 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
         stage_record<MODEL>(c, w, a, ch2, is_g, hl, xs, xe, d, dl, g, put);
     }
     __builtin_amdgcn_wave_barrier();
+    SOLO_CLK(recs, tclk);
     if (hl == 0 && live) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rc[f * N + k]; });
+    SOLO_CLK(adj, tclk);
 }
 
 // list of the agents of this view that are still running (phase != PH_DONE), in agent order inside a
@@ -130,7 +144,12 @@ __global__ void __launch_bounds__(64, 1) solo_eval_kernel(const DevCfg c, const 
     extern __shared__ double s_solo[];
     double *traj = s_solo;
     double *rec = traj + (size_t)(c.N + 1) * ModelDim<MODEL>::NX;
+#if MPC_DEV_STAMP == 5
+    SoloClk clk;
+    solo_eval<MODEL>(c, w, blockIdx.x, threadIdx.x, want_grad ? REQ_GRAD : REQ_COST, traj, rec, clk);
+#else
     solo_eval<MODEL>(c, w, blockIdx.x, threadIdx.x, want_grad ? REQ_GRAD : REQ_COST, traj, rec);
+#endif
 }
 
 // ctr[0] = claim counter, ctr[1] = number of list entries (list == nullptr: every agent of the view)
@@ -162,21 +181,29 @@ solo_kernel(const DevCfg c, const Workspace w, const int *__restrict__ list, int
         const int a = list ? list[i] : i;
 #if MPC_DEV_STAMP == 5
         const long long st0 = __builtin_amdgcn_s_memrealtime();
-        long long ntrip = 0;
+        long long ntrip = 0, t_adv = 0;
+        SoloClk clk;
 #endif
         for (long long trip = 0; trip < max_trips; trip++) {
+#if MPC_DEV_STAMP == 5
+            const long long ta = __builtin_amdgcn_s_memrealtime();
+#endif
             const AgentIn<NE> in = load_agent<NE>(c, w, a, lane);
             const int req = advance_agent<NE, MC>(c, w, a, lane, in, hist, false, /*allow_spec=*/spec);
             if ((req & (REQ_GRAD | REQ_COST)) == 0) break;              // uniform: the agent is done
-            solo_eval<MODEL>(c, w, a, lane, req, traj, rec);
 #if MPC_DEV_STAMP == 5
+            t_adv += __builtin_amdgcn_s_memrealtime() - ta;
+            solo_eval<MODEL>(c, w, a, lane, req, traj, rec, clk);
             ntrip++;
+#else
+            solo_eval<MODEL>(c, w, a, lane, req, traj, rec);
 #endif
         }
 #if MPC_DEV_STAMP == 5
         if (lane == 0 && i < DEV_STAMPS) {   // (one buffer for all groups: the claim index of the group whose kernel ran last wins)
             g_dev_stamps[4 * i] = st0; g_dev_stamps[4 * i + 1] = __builtin_amdgcn_s_memrealtime();
-            g_dev_stamps[4 * i + 2] = ntrip; g_dev_stamps[4 * i + 3] = a;
+            g_dev_stamps[4 * i + 2] = ntrip | (t_adv << 20); g_dev_stamps[4 * i + 3] = a | (clk.roll << 20);
+            if (i + 32768 < DEV_STAMPS) { g_dev_stamps[4 * (i + 32768)] = clk.recs; g_dev_stamps[4 * (i + 32768) + 1] = clk.adj; }
         }
 #endif
     }

@@ -22,8 +22,10 @@ torch.cuda.synchronize()
 info = eng.last_solve_info()
 assert L.mpc_dev_stamps(buf) == 0
 n = info["solo_agents"]
-a = np.frombuffer(buf, dtype=np.int64).reshape(-1, 4)[:n]
-t0, t1, trips, agent = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+full = np.frombuffer(buf, dtype=np.int64).reshape(-1, 4)
+a = full[:n]
+t0, t1, trips, agent = a[:, 0], a[:, 1], a[:, 2] & 0xFFFFF, a[:, 3] & 0xFFFFF
+t_adv, t_roll, t_recs, t_adj = a[:, 2] >> 20, a[:, 3] >> 20, full[32768:32768 + n, 0], full[32768:32768 + n, 1]
 base = t0.min()
 dur = (t1 - t0) / 100.0
 print("solo agents %d, rounds %d; kernel span %.1f ms; per agent: duration median %.0f us, 90%% %.0f, 99%% %.0f, max %.0f us; trips median %d max %d; us per trip median %.1f"
@@ -34,6 +36,9 @@ st = st.cpu().numpy()
 for i in order:
     print("   claim #%4d agent %6d: start %.2f ms, duration %.2f ms, %d trips (%.1f us per trip); evaluations of the whole solve %d, inner iterations %d"
           % (i, agent[i], (t0[i] - base) / 1e5, dur[i] / 1e3, trips[i], dur[i] / max(1, trips[i]), st[agent[i], 7], st[agent[i], 2]))
+i = order[0]
+print("the longest agent, per trip: load + step of the state machine %.1f us, rollout %.1f us, stage records %.1f us, adjoint %.1f us (of %.1f us)"
+      % (t_adv[i] / 100.0 / trips[i], t_roll[i] / 100.0 / trips[i], t_recs[i] / 100.0 / trips[i], t_adj[i] / 100.0 / trips[i], dur[i] / trips[i]))
 late = (t0 - base) / 100.0 > 50.0
 print("agents claimed later than 50 us after the start: %d; the latest claim at %.2f ms; work claimed late: %.1f ms of %.1f ms of wave time"
       % (late.sum(), (t0.max() - base) / 1e5, dur[late].sum() / 1e3, dur.sum() / 1e3))
