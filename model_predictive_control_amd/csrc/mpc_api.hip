@@ -1338,6 +1338,11 @@ extern "C" int mpc_set_profile(mpc_handle *h, int on)
 }
 
 #ifdef MPC_DEV_STAMP
+extern "C" int mpc_dev_records(mpc_handle *h, double *host_out)   // (experiment) the per-agent records as the last solve left them
+{
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(host_out, h->ws.rec, sizeof(double) * (size_t)h->ws.B * mpc::REC, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
 extern "C" int mpc_dev_stamps(long long *host_out)       // (timing experiment) the stamps of the last launch of the kernel chosen
 {
     (void)hipDeviceSynchronize();
