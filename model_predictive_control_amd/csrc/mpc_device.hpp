@@ -709,11 +709,7 @@ MPC_DEV bool kin4_in_range(const DevCfg &c, const StageInput<KIN> &u, const doub
     const double vmax = fabs(x[3]) + 2.0 * Ts * (fabs(u.ad) + fabs(c.friction * x[3]));
     const double dmax = c.h * vmax * fabs(u.sb_lr);
     const double amax = fabs(x[2]) + fabs(u.beta) + 4.0 * dmax;
-#ifdef MPC_DEV_ALWAYS_IN_RANGE
-    return amax == amax || true;                         // (timing experiment: what do the out-of-range lanes cost? WRONG results for them)
-#else
     return dmax <= 0.7 && amax < 1.0e5 && fabs(c.friction) * Ts <= 0.5;
-#endif
 }
 
 template <int MODEL>

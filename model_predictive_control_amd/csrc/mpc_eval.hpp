@@ -163,9 +163,6 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     bool redo = false;
     // lane `half` stores components 2 half and 2 half + 1 of every state
     auto put = [&](int k) {
-#ifdef MPC_DEV_K1A_NOSTORE
-        if (k < N) return;                                   // (timing experiment: only the last state is stored)
-#endif
         if (!active || redo) return;
         w.trajx[(size_t)(k * 4 + 2 * half) * St + uslot] = half ? x[2] : x[0];
         w.trajx[(size_t)(k * 4 + 2 * half + 1) * St + uslot] = half ? x[3] : x[1];
@@ -175,9 +172,7 @@ rollout_pair_kernel(const DevCfg c, const Workspace w, const int *__restrict__ l
     // two stages at a time, stage k + half by lane `half`, and handed to the partner by DPP
     auto stage = [&](int k, const StageInput<KIN> &u) {
         const double d = urow[2 * k], dl = urow[2 * k + 1];
-#ifndef MPC_DEV_K1A_NOSTORE
         if (active) w.useq[(size_t)(2 * k + half) * St + uslot] = half ? dl : d;
-#endif
         redo = redo || !kin4_in_range(c, u, x);          // (both lanes of a pair hold the same state)
 #if MPC_DEV_STAMP == 1
         if (__ballot(redo) != 0ull) stamp.nfall++;

@@ -1329,9 +1329,16 @@ step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
         }
 #if MPC_DEV_STAMP == 3
         stamp.nfall++;                                   // agent-steps of this wave
-        if (hist_ready) stamp.nmid++;
+        const long long tv0 = __builtin_amdgcn_s_memrealtime();
+        const int ph_in = __builtin_amdgcn_readlane(__double2loint(cur.rv), R_PHASE) & PH_MASK;
 #endif
         const int req = advance_agent<NE, MC, HASM>(c, w, a, lane, cur, hist, hist_ready, true, /*allow_chain=*/true, P);
+#if MPC_DEV_STAMP == 3
+        {   // the longest agent-step of this wave: its length in 10 ns ticks (nmid, capped at 255) and the phase it came in with (nslow)
+            const int dt = (int)(__builtin_amdgcn_s_memrealtime() - tv0);
+            if (dt > stamp.nmid) { stamp.nmid = dt > 255 ? 255 : dt; stamp.nslow = ph_in; }
+        }
+#endif
         if (lane == 0) s_req[loc] = req;
         loc = loc_next;
     }

@@ -44,6 +44,16 @@ for R in [int(a) for a in sys.argv[1:]] or [48, 152, 304]:
     # how many waves are resident over time
     ts = np.linspace(0, end.max(), 11)[1:-1]
     print("     waves resident at", " ".join("%.0f us:%d" % (t, ((start <= t) & (end > t) & live).sum()) for t in ts))
+    if os.environ.get("TRACE_STEP"):
+        n3 = (misc >> 24) & 255
+        import collections as cc
+        print("     longest agent-step per wave (x 10 ns): median %.0f, 90%% %.0f, 99%% %.0f, max %d (255 = capped); phase of the longest where it is >= 1.5 us: %s"
+              % (np.median(n2[live]), np.percentile(n2[live], 90), np.percentile(n2[live], 99), n2[live].max(),
+                 dict(sorted(cc.Counter(n3[live & (n2 >= 150)].tolist()).items()))))
+        print("     phase of the longest agent-step, all waves: %s" % dict(sorted(cc.Counter(n3[live].tolist()).items())))
+        late = live & (end > np.percentile(end[live], 95))
+        print("     the 5%% of the waves that end last: agent-steps median %.0f (all: %.0f), longest agent-step median %.0f x 10 ns (all: %.0f)"
+              % (np.median(n1[late]), np.median(n1[live]), np.median(n2[late]), np.median(n2[live])))
     if n1.max() > 0 and os.environ.get("TRACE_SLOW"):
         slow = live & (d > 2.0 * np.median(d[live]))
         print("     waves longer than twice the median: %d; of those with counter 1 > 0: %d, with counter 2 > 0: %d, neither: %d; among the others counter 1 > 0: %d, counter 2 > 0: %d"
