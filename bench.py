@@ -122,7 +122,8 @@ def pmc_profile():
     """HBM traffic per kernel launch from the committed rocprofv3 counter passes (tools_profile.sh ->
     tools_pmc_summary.py): the newest profiles/r*_pmc_summary.json, else profiles/pmc_summary.json."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    # (tags run r03a .. r03z, r03aa ..: shorter names first, then alphabetically)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=lambda f: (len(os.path.basename(f)), f))
     path = cands[-1] if cands else os.path.join(ROOT, "profiles", "pmc_summary.json")
     if not os.path.exists(path):
         return None, None
