@@ -613,6 +613,9 @@ stage_kernel(const DevCfg c, const Workspace w, const int *__restrict__ counts, 
              int nblk_max)
 {
     constexpr int NX = ModelDim<MODEL>::NX, JS = JacRec<MODEL>::SIZE;
+#if MPC_DEV_STAMP == 6
+    DevStamp stamp(blockIdx.x);
+#endif
     const SlotMap sm(counts, nG_imm, nC_imm);
     const int k = blockIdx.x / nblk_max, sb = blockIdx.x % nblk_max;
     if (sb >= sm.nblk) return;

@@ -96,7 +96,7 @@ struct Workspace {
 
 #ifdef MPC_DEV_STAMP
 // (timing experiments, never in the product build: -DMPC_DEV_STAMP=1 K1a (two lanes per request), 2 the fused K1b+K1c kernel,
-// 3 the step kernel, 4 K1a of the Pacejka model (four lanes per request))
+// 3 the step kernel, 4 K1a of the Pacejka model (four lanes per request), 5 the persistent kernel (per agent), 6 K1b (stage_kernel))
 // per wave of the last launch: start, end (100 MHz clock), HW_ID, XCC_ID | counters
 constexpr int DEV_STAMPS = 65536;
 __device__ long long g_dev_stamps[4 * DEV_STAMPS];
