@@ -124,3 +124,17 @@ def test_thread_serial_tree_sum_has_the_bits_of_the_wave_reduction():
             assert a == b and np.signbit(a) == np.signbit(b), (N, a, b)
             differs_from_sequential += a != float(np.add.reduce(v))
     assert differs_from_sequential > 100          # (the test can tell orders apart)
+
+
+def test_bench_reads_the_newest_counter_summary(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from the newest profiles/r*_pmc_summary.json; the tags run r03a .. r03z,
+    r03aa ..., so "newest" is shorter-names-first, then alphabetical (a plain sort put r03w after r03aw)."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for tag in ("r02e", "r03h", "r03w", "r03am", "r03aw"):
+        (prof / (tag + "_pmc_summary.json")).write_text(json.dumps({"tag": tag}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    pmc, src = bench.pmc_profile()
+    assert pmc["tag"] == "r03aw" and src.endswith("r03aw_pmc_summary.json")
