@@ -158,7 +158,10 @@ __global__ void __launch_bounds__(64, 1) solo_eval_kernel(const DevCfg c, const 
 // while twice as many agents are in flight (4 096 agents: 78 -> 53 ms).  The Pacejka variant needs all 512
 // and its long serial chains lose more to the spills than they gain (65 536 agents: 0.97 -> 1.01 s): one wave.
 // (the variant that caches twenty history pairs in registers cannot be held to 256 either)
-template <int MODEL, int MC> struct SoloOcc { static constexpr int WPS = (MODEL == KIN && MC <= 0) ? 2 : 1; };
+#ifndef MPC_SOLO_WPS_KIN
+#define MPC_SOLO_WPS_KIN 2
+#endif
+template <int MODEL, int MC> struct SoloOcc { static constexpr int WPS = (MODEL == KIN && MC <= 0) ? MPC_SOLO_WPS_KIN : 1; };
 
 template <int MODEL, int NE, int MC>
 __global__ void __launch_bounds__(64 * SOLO_WAVES, (SoloOcc<MODEL, MC>::WPS))
