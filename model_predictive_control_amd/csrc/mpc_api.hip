@@ -47,6 +47,7 @@ struct mpc_handle {
                                  // (same bits; measured 3 % slower -- write-through record stores: DESIGN.md 6)
     int *arrive_buf = nullptr;  // arrival counters, one per block of 64 slots
     bool quad_rollout = true;   // K1a by two (kinematic) / four (Pacejka) lanes per request (MPC_NO_QUAD: one thread)
+    int pac_quad_max = 24576;   // Pacejka: requests bound of a round up to which K1a runs four lanes per request (MPC_PAC_QUAD_MAX)
     bool step_regs = false;     // MPC_STEP_REGS at mpc_create: history rows cached in registers, not LDS
     int chain_min = 24576;      // MPC_CHAIN_MIN: requests bound of a group's round from which the thread-per-agent blocks
                                 // (chain_block) ride in its step launch.  Measured with the one-wave form (r03_experiments 18):
@@ -272,6 +273,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (getenv("MPC_LDS_PAIRS")) h->lds_pairs = atoi(getenv("MPC_LDS_PAIRS"));
     if (getenv("MPC_CHAIN_MIN")) h->chain_min = atoi(getenv("MPC_CHAIN_MIN"));
     h->quad_rollout = getenv("MPC_NO_QUAD") == nullptr;
+    if (getenv("MPC_PAC_QUAD_MAX")) h->pac_quad_max = atoi(getenv("MPC_PAC_QUAD_MAX"));
     h->arrive_adjoint = getenv("MPC_ARRIVE") != nullptr;
     if (getenv("MPC_WIDE_MAX")) h->wide_max = atoi(getenv("MPC_WIDE_MAX"));
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
@@ -417,7 +419,11 @@ static bool launch_eval_t(mpc_handle *h, const Workspace &w, hipStream_t s, cons
                                sizeof(double) * 32 * (size_t)(c.n + 1), s, c, w, lists, counts, nG, nC);
     }
     if constexpr (MODEL == PAC) {
-        quad = h->quad_rollout;
+        // four lanes per request while a round holds few requests (a shorter chain per request where waves are alone on
+        // their SIMDs); one thread per request -- 2.2 times fewer instructions in all -- once the launch fills the chip
+        // (pac_quad_max: requests bound up to which the four-lane kernel runs; since the lost stages are parked no
+        // request drags its wave, and the full rounds are bound by what they execute: profiles/r03_experiments.txt 34)
+        quad = h->quad_rollout && !(counts && slot_bound >= 0 && slot_bound > h->pac_quad_max);
         if (quad)
             hipLaunchKernelGGL(rollout_quad_kernel, dim3((unsigned)(nblk * 4)), dim3(64),
                                sizeof(double) * 16 * (size_t)(c.n + 1), s, c, w, lists, counts, nG, nC);

@@ -844,6 +844,14 @@ def test_quad_rollout_is_bit_identical(dev, monkeypatch, model, N):
     Ut_, _, stt = et.solve(X0, cl, U0)
     same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1.25), torch.nan_to_num(b, nan=1.25))
     assert same(pq, pt) and same(gq, gt) and same(Uq, Ut_) and same(stq, stt)
+    if model == 1:
+        # the Pacejka rounds choose per launch: one thread per request while a round is full, four lanes once it holds
+        # fewer requests than MPC_PAC_QUAD_MAX / 2 -- here the switch falls inside the solve
+        monkeypatch.setenv("MPC_PAC_QUAD_MAX", "300")
+        em = mp.BatchedMPC(cfg, dev)
+        monkeypatch.delenv("MPC_PAC_QUAD_MAX")
+        Um, _, stm = em.solve(X0, cl, U0)
+        assert same(Uq, Um) and same(stq, stm)
     fin = torch.isfinite(pq)
     assert fin.float().mean() >= 0.9 and (stq[:, 0] == 1).float().mean() >= (0.8 if N <= 20 else 0.3)
 
