@@ -45,6 +45,7 @@ enum { MPC_OK = 0, MPC_E_ARG = -1, MPC_E_HIP = -2, MPC_E_ALLOC = -3, MPC_E_LIMIT
 
 #define MPC_NSTATS 8 /* [status, outer_iters, inner_iters, inner_failures, eps, delta, psi, n_evals] */
 #define MPC_MAX_N 64 /* horizon limit */
+#define MPC_NREC 64  /* doubles per agent of mpc_debug_records */
 
 typedef struct mpc_config {
     int32_t model;           /* MPC_MODEL_* */
@@ -88,6 +89,10 @@ int mpc_m(const mpc_config *cfg);
 int mpc_create(const mpc_config *cfg, int device, mpc_handle **out);
 int mpc_destroy(mpc_handle *h);
 const char *mpc_last_error(void);
+/* identity of the build: SHA-256 over the library's sources and this header as _lib.build() compiled them
+ * ("unknown" for a build by other means).  Committed profiles name the build they measured by it and bench.py
+ * uses a profile's counters only when it matches the running library. */
+const char *mpc_source_hash(void);
 
 /* a-1 (car_dynamics.py:93-132 / dynamics.py:67-119,:144-173): dx[B][nx] = f(x[B][nx], u[B][2]) */
 int mpc_rhs(mpc_handle *h, int B, const double *x, const double *u, double *dx, void *stream);
@@ -206,6 +211,14 @@ int mpc_last_solo_ms(mpc_handle *h, double *sum_ms, double *longest_ms);
  * batches up to 4096 agents (kinematic, N <= 32) / 1024 (otherwise); environment
  * MPC_SOLO_MAX (both) and MPC_SOLO_ALL (the batch bound alone).  Results do not depend on it. */
 int mpc_set_solo_max(mpc_handle *h, int max_requests);
+/* Two more per-launch kernel choosers, environment only (read at mpc_create; results do not depend on them):
+ *   MPC_PAC_QUAD_MAX  Pacejka model: requests bound of a round up to which K1a runs four lanes per request
+ *                     (rollout_quad_kernel); above it one thread per request (default 24576: the four-lane kernel
+ *                     shortens a lone wave's chain, the thread kernel executes 2.2x fewer instructions).
+ *   MPC_CHAIN_MIN     requests bound of a group's round from which the step launch carries the thread-per-agent
+ *                     blocks that serve agents waiting for a trial point's gradient (default 24576: full rounds of
+ *                     groups of more than 12288 agents; kinematic model only unless this variable is set);
+ *                     MPC_NO_CHAIN = never. */
 /* sub-batch pipelining: the batch is split into `groups` contiguous ranges whose rounds run on
  * separate HIP streams (0 = automatic: 4 from 49152 agents when the runtime runs five streams side by
  * side -- measured at mpc_create, see mpc_stream_concurrency --, 3 from 24576, 2 from 16384, else 1; at
@@ -227,6 +240,25 @@ int mpc_set_memo(mpc_handle *h, int on);
  * needs more returns MPC_E_LIMIT with the agents it could not finish left as they are (0 = the built-in
  * guard alone, which no valid solve reaches) */
 int mpc_set_round_limit(mpc_handle *h, int64_t rounds);
+/* Wall-clock bound of a solve's host side (default 300 s; environment MPC_POLL_TIMEOUT_S at mpc_create).  The
+ * round loop of mpc_solve_batch is host code that polls device counters: when NO polled window has completed
+ * for `seconds`, or one of the blocking waits behind the loop has lasted that long, the call returns MPC_E_HIP
+ * ("wall-clock bound ... expired") instead of waiting for ever on a device that does not answer.  It does NOT
+ * synchronise the device on that path (that would be the same hang): kernels of the solve may still be queued and
+ * the caller's U / lambda / stats buffers are in use until the caller has synchronised the device itself.  A
+ * valid solve never comes near the default (a 65 536-agent solve completes a window every ~3 ms). */
+int mpc_set_poll_timeout(mpc_handle *h, double seconds);
+/* test aid: queues the library's idling kernel (one wavefront sleeping for `microseconds` of the device wall
+ * clock, at most 30 s) on `stream` */
+int mpc_debug_spin(mpc_handle *h, double microseconds, void *stream);
+/* diagnostic: the per-agent solver records as the last solve left them, decoded to plain doubles, copied to the
+ * HOST array host_out [B][MPC_NREC] (B <= the last solve's batch); mpc_debug_record_names() = the comma-separated
+ * names of the slots in use (step sizes L / gamma, accepted line-search step tau (halved), |J|, history fill,
+ * evaluation counters ...).  After a solve stopped by max_total_inner = k the records hold the solver state after
+ * k inner iterations: what tests/test_gpu_parity.py::test_iterate_prefix_parity and tools/dev/first_divergence.py
+ * compare with the oracle's per-iteration trace.  Synchronises the device. */
+int mpc_debug_records(mpc_handle *h, int B, double *host_out);
+const char *mpc_debug_record_names(void);
 /* on != 0: bracket every kernel of mpc_solve_batch with HIP events on the solve's stream so that
  * mpc_last_solve_info reports eval_ms / step_ms (also enabled by the environment MPC_PROFILE=1) */
 int mpc_set_profile(mpc_handle *h, int on);

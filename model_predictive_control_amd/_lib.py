@@ -47,7 +47,9 @@ EXPORTS = [
     "mpc_set_profile", "mpc_last_speculation", "mpc_last_kernel_profile", "mpc_set_solo_max",
     "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks", "mpc_set_memo",
     "mpc_set_round_limit", "mpc_stream_concurrency", "mpc_last_solo_ms",
+    "mpc_set_poll_timeout", "mpc_debug_spin", "mpc_debug_records", "mpc_debug_record_names", "mpc_source_hash",
 ]
+NREC = 64
 
 
 class MpcConfig(C.Structure):
@@ -74,13 +76,24 @@ class MpcConfig(C.Structure):
     ]
 
 
+def source_hash():
+    """SHA-256 over the library's sources and its header, in a fixed order: what `build()` compiles into the
+    library as its identity (mpc_source_hash) and what a committed profile names as the build it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in _SRC + [_HDR]:
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """hipcc cross-compiles the library for gfx950 (works without a GPU)."""
     newest = max(os.path.getmtime(p) for p in _SRC + [_HDR])
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB_PATH, _SRC[0]]
+           "-DMPC_SOURCE_SHA256=\"%s\"" % source_hash(), "-o", LIB_PATH, _SRC[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_HERE)
@@ -138,8 +151,13 @@ def load():
     L.mpc_set_round_limit.argtypes = [vp, C.c_int64]
     L.mpc_last_solo_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mpc_stream_concurrency.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mpc_set_poll_timeout.argtypes = [vp, C.c_double]
+    L.mpc_debug_spin.argtypes = [vp, C.c_double, vp]
+    L.mpc_debug_records.argtypes = [vp, ci, vp]
+    L.mpc_debug_record_names.restype = C.c_char_p
+    L.mpc_source_hash.restype = C.c_char_p
     for name in EXPORTS:
-        if name != "mpc_last_error":
+        if name not in ("mpc_last_error", "mpc_debug_record_names", "mpc_source_hash"):
             getattr(L, name).restype = ci
     _lib = L
     return L
@@ -159,6 +177,11 @@ def default_config(model=MODEL_PACEJKA, N=12, **overrides):
         else:
             setattr(cfg, k, v)
     return cfg
+
+
+def library_hash():
+    """The source hash the RUNNING library was built from (mpc_source_hash)."""
+    return load().mpc_source_hash().decode()
 
 
 class MpcError(RuntimeError):

@@ -104,7 +104,13 @@ struct mpc_handle {
     int ngroups = 0; // 0 = choose from the batch size
     int groups_last = 0; // sub-batch groups of the last solve
     long long round_limit = 0; // mpc_set_round_limit: cap on the rounds / persistent-kernel trips of a solve (0 = the guard alone)
-    int hw_queues = 4; // streams of this process the HIP runtime runs side by side: 5 (or more) / 4 (or fewer), measured at mpc_create
+    int hw_queues = 4; // streams of this process the HIP runtime runs side by side: 5 (or more) / 4 (or fewer), measured once per
+                       // process and device (probe_stream_concurrency)
+    double poll_timeout_s = 300.0; // wall-clock bound of a solve's host waits (mpc_set_poll_timeout / MPC_POLL_TIMEOUT_S): the
+                                   // round loop gives up when no polled window has completed for this long, the blocking waits
+                                   // behind it when they have lasted this long.  A valid solve never comes near it.
+    bool timed_out = false;        // the last solve ended on that bound: work may still be queued on the device
+    hipEvent_t syncev = nullptr;   // bounded_sync
     hipStream_t gstream[MPC_MAX_GROUPS] = {};
     hipEvent_t gevent[MPC_MAX_GROUPS + 1] = {};
     // staging buffers for the standalone entry points
@@ -113,6 +119,10 @@ struct mpc_handle {
 };
 
 extern "C" const char *mpc_last_error(void) { return g_err.c_str(); }
+#ifndef MPC_SOURCE_SHA256
+#define MPC_SOURCE_SHA256 "unknown"
+#endif
+extern "C" const char *mpc_source_hash(void) { return MPC_SOURCE_SHA256; }
 
 extern "C" int mpc_default_config(mpc_config *c, int model, int N)
 {
@@ -231,30 +241,49 @@ __global__ void spin_kernel(long long ticks)
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
-static int probe_stream_concurrency(mpc_handle *h)
+static int probe_stream_concurrency_once(int device)
 {
     int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
     const double spin_us = 250.0;
     const long long ticks = (long long)(spin_us * 1e-6 * khz * 1e3);
+    // five private non-blocking streams (not the null stream: a probe must neither wait for nor hold up the caller's
+    // other streams, and must work while the caller is capturing a graph elsewhere); only they are synchronised
     hipStream_t st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    for (int g = 0; g < 4; g++) {
-        if (!h->gstream[g] && hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking) != hipSuccess) return 4;
-        st[g + 1] = h->gstream[g];
+    int result = 4;
+    bool ok = true;
+    for (int k = 0; k < 5 && ok; k++) ok = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[0], 1LL);    // code object load, first-launch costs
+        ok = hipStreamSynchronize(st[0]) == hipSuccess;
     }
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[0], 1LL);    // code object load, first-launch costs
-    if (hipDeviceSynchronize() != hipSuccess) return 4;
     double best = 1e30;
-    for (int rep = 0; rep < 3; rep++) {
+    // three samples; when even the best of them looks like a shared queue AND like a busy device (more than three spins:
+    // another handle's solve was running beside the probe), sample again a few times before settling for "four"
+    for (int rep = 0; rep < 9 && ok; rep++) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int k = 0; k < 5; k++) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[k], ticks);
-        for (int k = 0; k < 5; k++) if (hipStreamSynchronize(st[k]) != hipSuccess) return 4;
+        for (int k = 0; k < 5 && ok; k++) ok = hipStreamSynchronize(st[k]) == hipSuccess;
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         best = std::min(best, us);
+        if (rep >= 2 && !(best > 3.0 * spin_us)) break;
     }
     (void)hipGetLastError();
+    for (int k = 0; k < 5; k++) if (st[k]) (void)hipStreamDestroy(st[k]);
     // five side by side: ~ one spin (+ launch overheads); a shared queue: two spins or more
-    return best < 1.6 * spin_us ? 5 : 4;
+    if (ok) result = best < 1.6 * spin_us ? 5 : 4;
+    return result;
+}
+// measured once per (process, device): the answer is a property of the runtime's queue setup, not of the handle, and a
+// handle created while another one is solving must not keep a pessimistic sample for its lifetime
+static int probe_stream_concurrency(mpc_handle *h)
+{
+    static std::mutex mu;
+    static int cached[64];
+    std::lock_guard<std::mutex> lk(mu);
+    const int d = h->device >= 0 && h->device < 64 ? h->device : 0;
+    if (cached[d] == 0) cached[d] = probe_stream_concurrency_once(h->device);
+    return cached[d];
 }
 
 extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
@@ -298,6 +327,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (e != hipSuccess) { delete h; return fail(MPC_E_HIP, std::string("mpc_create: ") + hipGetErrorString(e)); }
     const char *p = getenv("MPC_PROFILE");
     h->profile = p && p[0] == '1';
+    if (getenv("MPC_POLL_TIMEOUT_S")) { const double t = atof(getenv("MPC_POLL_TIMEOUT_S")); if (t > 0.0) h->poll_timeout_s = t; }
     const char *gq = getenv("MPC_GROUPS");
     h->ngroups = gq ? atoi(gq) : 0;
     // (MPC_HW_QUEUES overrides the measurement: experiments only)
@@ -322,6 +352,7 @@ extern "C" int mpc_destroy(mpc_handle *h)
     if (h->cl_gxy) (void)hipFree(h->cl_gxy);
     if (h->cl_gcells) (void)hipFree(h->cl_gcells);
     if (h->host_counts) (void)hipHostFree(h->host_counts);
+    if (h->syncev) (void)hipEventDestroy(h->syncev);
     for (auto ev : h->ev_pool) (void)hipEventDestroy(ev);
     for (int g = 0; g < MPC_MAX_GROUPS; g++) if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
     for (int g = 0; g <= MPC_MAX_GROUPS; g++) if (h->gevent[g]) (void)hipEventDestroy(h->gevent[g]);
@@ -811,6 +842,30 @@ static bool solo_fits(const mpc_handle *h)
     return c.N <= 64 && per * SOLO_WAVES * sizeof(double) <= 64 * 1024;
 }
 
+// hipStreamSynchronize with the handle's wall-clock bound: an event behind everything queued on `s`, polled in naps.
+// Returns MPC_OK, or MPC_E_HIP with h->timed_out set when the bound expired (work is then still queued).
+static int bounded_sync(mpc_handle *h, hipStream_t s, const char *what)
+{
+    if (!h->syncev) HIPCHK(hipEventCreateWithFlags(&h->syncev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->syncev, s));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(h->syncev);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(MPC_E_HIP, std::string(what) + ": " + hipGetErrorString(q));
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > h->poll_timeout_s) {
+            h->timed_out = true;
+            return fail(MPC_E_HIP, std::string(what) + ": wall-clock bound of " + std::to_string(h->poll_timeout_s) +
+                                   " s expired while waiting for the device (mpc_set_poll_timeout); work is still queued");
+        }
+        if (waited < 100e-6) __builtin_ia32_pause();
+        else std::this_thread::sleep_for(std::chrono::microseconds(waited < 5e-3 ? 20 : 200));
+    }
+    (void)hipGetLastError();   // (the queries that said "not ready" left that as the thread's last error)
+    return MPC_OK;
+}
+
 // a view of the workspace restricted to agents [lo, hi): local agent ids, own lists / scratch
 static Workspace group_view(const Workspace &w, const DevCfg &c, int g, int lo, int hi)
 {
@@ -841,11 +896,19 @@ static Workspace group_view(const Workspace &w, const DevCfg &c, int g, int lo, 
 static int run_solver_rounds(mpc_handle *h, hipStream_t s);
 static int run_solver(mpc_handle *h, hipStream_t s)
 {
+    h->timed_out = false;
     const int rc = run_solver_rounds(h, s);
     // On any failure rounds may still be queued on the sub-batch streams (non-blocking streams: a
     // wait on `s` does not cover them) and they write into the caller's U / lambda and the arena:
-    // nothing is handed back to the caller before the device has drained.
-    if (rc != MPC_OK) (void)hipDeviceSynchronize();
+    // nothing is handed back to the caller before the device has drained -- EXCEPT after the wall-clock
+    // bound: the device is not answering, a blocking wait would be the hang the bound exists to end.  The
+    // caller gets MPC_E_HIP and must treat the buffers of this solve as in use until it has synchronised the
+    // device itself (or given up on it).
+    if (rc != MPC_OK && !h->timed_out) {
+        const std::string keep = g_err;
+        (void)hipDeviceSynchronize();
+        g_err = keep;
+    }
     return rc;
 }
 static int run_solver_rounds(mpc_handle *h, hipStream_t s)
@@ -1046,6 +1109,9 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
             queue_window(g);
         }
         if (progressed) { last_progress = std::chrono::steady_clock::now(); continue; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - last_progress).count() > h->poll_timeout_s) {
+            h->timed_out = true; rc_loop = MPC_E_HIP; break;      // no window has completed for poll_timeout_s
+        }
         if (spin_only || std::chrono::steady_clock::now() - last_progress < std::chrono::microseconds(40))
             __builtin_ia32_pause();
         else
@@ -1064,6 +1130,9 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         }
     }
     if (rc_loop == MPC_E_LIMIT) return fail(MPC_E_LIMIT, "mpc_solve_batch: round limit reached");
+    if (h->timed_out)
+        return fail(MPC_E_HIP, "mpc_solve_batch: wall-clock bound of " + std::to_string(h->poll_timeout_s) +
+                               " s expired in the round loop: no polled window completed (mpc_set_poll_timeout); work is still queued");
     if (rc_loop != MPC_OK) return fail(rc_loop, "mpc_solve_batch: HIP error in the round loop");
     {
         const hipError_t le = hipGetLastError();
@@ -1082,7 +1151,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
         hipLaunchKernelGGL(totals_kernel, grid_for(B, 256), dim3(256), 0, s, w);
         HIPCHK(hipMemcpyAsync(tot, w.totals, sizeof tot, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(sctr, w.solo_ctr, sizeof sctr, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        { const int rs = bounded_sync(h, s, "mpc_solve_batch"); if (rs) return rs; }
         h->evals_grad = (int64_t)tot[0]; h->evals_cost = (int64_t)tot[1]; h->lbfgs_rows = (int64_t)tot[2];
         h->spec_issued = (int64_t)tot[4]; h->spec_used = (int64_t)tot[5];
         if (all_solo) h->solo_agents = B;
@@ -1094,7 +1163,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
                                      " agents unfinished in the persistent kernel)");
     }
     if (h->profile) {
-        HIPCHK(hipStreamSynchronize(s));
+        { const int rs = bounded_sync(h, s, "mpc_solve_batch"); if (rs) return rs; }
         for (size_t i = 0; i + 4 < nev; i += 5) {
             for (int k = 0; k < 4; k++) {
                 float d = 0.f;
@@ -1150,8 +1219,7 @@ static int solve_batch_impl(mpc_handle *h, int B, const double *x0, const double
     rc = run_solver(h, s); if (rc) return rc;
     if (stats) hipLaunchKernelGGL(stats_kernel, grid_for(B, 256), dim3(256), 0, s, w, stats);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
-    return MPC_OK;
+    return bounded_sync(h, s, "mpc_solve_batch");
 }
 
 // The round loop of a solve is host code (launches, counter polls): the asynchronous form runs it on a
@@ -1235,6 +1303,7 @@ extern "C" int mpc_closed_loop(mpc_handle *h, int B, int T, int shift, double *x
 extern "C" int mpc_last_speculation(mpc_handle *h, int64_t *issued, int64_t *used)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_speculation: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_last_speculation"); if (rb) return rb; }
     if (issued) *issued = h->spec_issued;
     if (used) *used = h->spec_used;
     return MPC_OK;
@@ -1243,6 +1312,7 @@ extern "C" int mpc_last_speculation(mpc_handle *h, int64_t *issued, int64_t *use
 extern "C" int mpc_last_solve_info2(mpc_handle *h, double *launch_pairs, int64_t *lbfgs_rows)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_solve_info2: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_last_solve_info2"); if (rb) return rb; }
     if (launch_pairs) *launch_pairs = (double)h->launches; // (step, eval) launch sets of the last solve
     if (lbfgs_rows) *lbfgs_rows = h->lbfgs_rows;
     return MPC_OK;
@@ -1252,6 +1322,7 @@ extern "C" int mpc_last_solve_info(mpc_handle *h, int64_t *rounds, int64_t *eval
                                    double *eval_ms, double *step_ms)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_solve_info: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_last_solve_info"); if (rb) return rb; }
     if (rounds) *rounds = h->rounds;
     if (evals_grad) *evals_grad = h->evals_grad;
     if (evals_cost) *evals_cost = h->evals_cost;
@@ -1263,6 +1334,7 @@ extern "C" int mpc_last_solve_info(mpc_handle *h, int64_t *rounds, int64_t *eval
 extern "C" int mpc_last_kernel_ms(mpc_handle *h, double *out4)
 {
     if (!h || !out4) return fail(MPC_E_ARG, "mpc_last_kernel_ms: null argument");
+    { const int rb = refuse_if_busy(h, "mpc_last_kernel_ms"); if (rb) return rb; }
     for (int k = 0; k < 4; k++) out4[k] = h->kernel_ms[k];
     return MPC_OK;
 }
@@ -1270,6 +1342,7 @@ extern "C" int mpc_last_kernel_ms(mpc_handle *h, double *out4)
 extern "C" int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int64_t *solo_agents)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_kernel_profile: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_last_kernel_profile"); if (rb) return rb; }
     for (int k = 0; k < 5; k++) {
         if (ms5) ms5[k] = h->kernel_ms[k];
         if (launches5) launches5[k] = h->kernel_launches[k];
@@ -1298,6 +1371,7 @@ extern "C" int mpc_set_solo_max(mpc_handle *h, int max_requests)
 extern "C" int mpc_last_solo_ms(mpc_handle *h, double *sum_ms, double *longest_ms)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_solo_ms: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_last_solo_ms"); if (rb) return rb; }
     if (sum_ms) *sum_ms = h->kernel_ms[4];
     if (longest_ms) *longest_ms = h->solo_longest_ms;
     return MPC_OK;
@@ -1306,6 +1380,7 @@ extern "C" int mpc_last_solo_ms(mpc_handle *h, double *sum_ms, double *longest_m
 extern "C" int mpc_stream_concurrency(mpc_handle *h, int *streams, int *groups_last)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_stream_concurrency: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_stream_concurrency"); if (rb) return rb; }
     if (streams) *streams = h->hw_queues;
     if (groups_last) *groups_last = h->groups_last;
     return MPC_OK;
@@ -1340,6 +1415,54 @@ extern "C" int mpc_set_profile(mpc_handle *h, int on)
     if (!h) return fail(MPC_E_ARG, "mpc_set_profile: null handle");
     { const int rb = refuse_if_busy(h, "mpc_set_profile"); if (rb) return rb; }
     h->profile = on != 0;
+    return MPC_OK;
+}
+
+extern "C" int mpc_set_poll_timeout(mpc_handle *h, double seconds)
+{
+    if (!h || !(seconds > 0.0)) return fail(MPC_E_ARG, "mpc_set_poll_timeout: bad argument");
+    { const int rb = refuse_if_busy(h, "mpc_set_poll_timeout"); if (rb) return rb; }
+    h->poll_timeout_s = seconds;
+    return MPC_OK;
+}
+
+// test aid: the library's idling kernel (one wave that sleeps until `microseconds` of the device's wall clock have
+// passed) queued on `stream` -- work that holds a stream for a known time (the wall-clock bound's test)
+extern "C" int mpc_debug_spin(mpc_handle *h, double microseconds, void *stream)
+{
+    int rc = check_common(h, 0, "mpc_debug_spin"); if (rc) return rc;
+    if (!(microseconds >= 0.0) || microseconds > 30e6) return fail(MPC_E_ARG, "mpc_debug_spin: 0 .. 30 s");
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(microseconds * 1e-6 * khz * 1e3));
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+// diagnostic: the per-agent solver records as the last solve left them (after a solve stopped by max_total_inner = k
+// they hold the state at the top of inner iteration k: step sizes, line-search step, active-set size, history
+// fill, counters), decoded to plain doubles, into a HOST array [B][MPC_NREC]; names: mpc_debug_record_names()
+static const char *const k_record_names =
+    "psi,L,gamma,phi,psixh,pp,gp,tau,psin,Ln,gamman,psixhn,gpn,ppn,sigpp,eps,hn2,hfd,gamma_top,Delta,rho,eps_old,ne1,ps_eps,"
+    "out_eps,out_delta,psi_out,psie,phase,k,lidx,lfull,noprog,nJ,outer,first,initred,penred,inner_tot,inner_fail,status,"
+    "nevals,maxit,overwrite,fallback,ps_status,ps_iters,out_of_iter,ngrad,lbrows,spec,spec_gamma,nspec,nspec_used,ncost,"
+    "run_mineps,run_ev0,memo_status,memo_iters,memo_evals,memo_mineps,memo_eps";
+static_assert(R_USED == 62 && REC == MPC_NREC, "k_record_names / MPC_NREC must follow the record enum");
+extern "C" const char *mpc_debug_record_names(void) { return k_record_names; }
+extern "C" int mpc_debug_records(mpc_handle *h, int B, double *host_out)
+{
+    int rc = check_common(h, B, "mpc_debug_records"); if (rc) return rc;
+    if (!host_out) return fail(MPC_E_ARG, "mpc_debug_records: null buffer");
+    if (B == 0) return MPC_OK;
+    if (!h->arena || B > h->ws.B) return fail(MPC_E_ARG, "mpc_debug_records: more agents than the last solve held");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_out, h->ws.rec, sizeof(double) * (size_t)B * REC, hipMemcpyDeviceToHost));
+    for (int a = 0; a < B; a++)
+        for (int sl = 0; sl < REC; sl++)
+            if (rec_is_int(sl)) {
+                int64_t bits; std::memcpy(&bits, &host_out[(size_t)a * REC + sl], 8);
+                host_out[(size_t)a * REC + sl] = (double)(int32_t)(bits & 0xffffffffLL);
+            }
     return MPC_OK;
 }
 

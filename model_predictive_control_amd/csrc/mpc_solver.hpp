@@ -1161,14 +1161,19 @@ __device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w,
     if (threadIdx.x >= 64) return;
     const int n = c.n, N = c.N, ld = n + 1, t = threadIdx.x;
     const int slot0 = cb * CHAIN_SLOTS;
-    if (slot0 >= gpad) return;                           // uniform: no gradient slots here
+    // Bound guards (round 4; uniform, off the hot path): the slot count comes from a device counter and the agent ids
+    // from the slot table of the finished round -- neither is trusted further than the arrays they index.  A view holds
+    // at most one gradient request per agent (<= Bp slots, padded to 64) inside its 2 Bp + 64 slot interval, its lists
+    // hold Bp entries each, and an agent id is < B.
+    if (gpad > w.Bp + 64) gpad = w.Bp + 64;
+    if (slot0 < 0 || slot0 >= gpad) return;              // uniform: no gradient slots here
     double *tA = lds;
     int *s_agent = (int *)(tA + CHAIN_SLOTS * ld);       // agent of the slot or -1
     const int total = CHAIN_SLOTS * n;
     {
         const int uslot = slot0 + t;
         const int raw = uslot < gpad ? w.agent_of[uslot] : -1;
-        const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0;
+        const bool on = raw >= 0 && (raw & CHAIN_BIT) != 0 && (raw & CH2_BIT) == 0 && (raw & AGENT_MASK) < w.B;
         s_agent[t] = on ? (raw & AGENT_MASK) : -1;
     }
     __builtin_amdgcn_wave_barrier();                     // one wave: LDS is in order
@@ -1225,9 +1230,9 @@ __device__ __forceinline__ void chain_block(const DevCfg &c, const Workspace &w,
         r[R_NEVALS] = rec_int(rec_int_of(r[R_NEVALS]) + 1); r[R_NCOST] += 1.0;
         r[R_PHASE] = rec_int(PH_W_LS_C + chain_tag(par));
         const int pc = wave_append(&counts_out[1], true);
-        lists_out[(size_t)w.Ls + pc] = a;
+        if (pc >= 0 && pc < w.Bp) lists_out[(size_t)w.Ls + pc] = a;
         const int pg = wave_append(&counts_out[0], spec);
-        if (spec) lists_out[pg] = a | CH2_BIT;
+        if (spec && pg >= 0 && pg < w.Bp) lists_out[pg] = a | CH2_BIT;
     }
     __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < total; base += 64 * 8) {   // the tile (now xhat+) -> xe rows

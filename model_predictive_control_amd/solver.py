@@ -93,18 +93,27 @@ class BatchedMPC:
         if self._nearest_blocks:
             # f-2: the tables of the pruned nearest-point searches for this centerline table (three small
             # kernels: ~30 us for one row, but 65 536 cells x 2 (S - 1) points and 256 KB of cells PER ROW for a
-            # table of many rows).  Rebuilt only when the table is another one or has been written to since
-            # (torch counts in-place writes in `_version`; the engine keeps the tensor alive meanwhile, so its
-            # address cannot be handed to another table).  A table changed behind torch's back -- by a raw
-            # kernel on its pointer -- needs `invalidate_centerline_tables()`.
-            # (the stream is part of the key: the tables are built by kernels on the caller's current stream, and a
-            # call on another stream must not read them before those kernels have run)
-            key = (cl.data_ptr(), tuple(cl.shape), cl._version, self._nearest_blocks,
-                   torch.cuda.current_stream(self.device).cuda_stream)
-            if key != self._cl_key:
+            # table of many rows).
+            # A ONE-ROW table (the shared centerline of main.py) is rebuilt on every call: the caller may have
+            # refreshed it in place by any route -- `cl.data.copy_()`, DLPack, a raw kernel -- and no host-side
+            # key sees all of them; 30 us on a solve of milliseconds.
+            # A table of SEVERAL rows is rebuilt only when it is another table or its contents have changed: the
+            # key holds the address, the shape, torch's in-place write counter, the stream (the tables are built by
+            # kernels on the caller's current stream, and a call on another stream must not read them before those
+            # kernels have run) AND a checksum of the table's bits computed on the device at every call (one
+            # reduction over C x 2S words, ~20 us, against ~1 ms of table building per 64 rows) -- a write behind
+            # torch's back (`.data`, DLPack, a raw kernel) changes the checksum.  The engine keeps the tensor
+            # alive meanwhile, so its address cannot be handed to another table.
+            if cl.shape[0] == 1:
                 self._cl_key, self._cl_keep = None, None
-                _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
-                self._cl_key, self._cl_keep = key, cl
+                _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), 1, self._stream()))
+            else:
+                key = (cl.data_ptr(), tuple(cl.shape), cl._version, self._nearest_blocks,
+                       torch.cuda.current_stream(self.device).cuda_stream, int(cl.view(torch.int64).sum().item()))
+                if key != self._cl_key:
+                    self._cl_key, self._cl_keep = None, None
+                    _lib.check(self.lib.mpc_centerline_blocks(self._h, _ptr(cl), int(cl.shape[0]), self._stream()))
+                    self._cl_key, self._cl_keep = key, cl
         return cl
 
     def invalidate_centerline_tables(self):
@@ -315,9 +324,28 @@ class BatchedMPC:
         finish inside it returns MPC_E_LIMIT.  0 = the built-in guard alone."""
         _lib.check(self.lib.mpc_set_round_limit(self._h, int(rounds)))
 
+    def set_poll_timeout(self, seconds):
+        """Wall-clock bound of a solve's host-side waits (default 300 s): a solve whose device stops answering
+        raises MpcError (MPC_E_HIP) instead of blocking for ever; the device is NOT synchronised on that path."""
+        _lib.check(self.lib.mpc_set_poll_timeout(self._h, float(seconds)))
+
+    def debug_spin(self, microseconds):
+        """Test aid: queue the library's idling kernel on the current stream for `microseconds`."""
+        _lib.check(self.lib.mpc_debug_spin(self._h, float(microseconds), self._stream()))
+
+    def debug_records(self, B):
+        """Diagnostic: {name: array[B]} of the per-agent solver records as the last solve left them."""
+        import numpy as np
+        self._free()
+        out = np.empty((int(B), _lib.NREC))
+        _lib.check(self.lib.mpc_debug_records(self._h, int(B), C.c_void_p(out.ctypes.data)))
+        names = self.lib.mpc_debug_record_names().decode().split(",")
+        return {nm: out[:, i] for i, nm in enumerate(names)}
+
     def stream_concurrency(self):
-        """(streams the HIP runtime runs side by side for this process -- 5 means five or more, measured when
-        the engine was created --, sub-batch groups of the last solve)."""
+        """(streams the HIP runtime runs side by side for this process -- 5 means five or more, measured once
+        per process and device --, sub-batch groups of the last solve)."""
+        self._free()
         a, b = C.c_int(), C.c_int()
         _lib.check(self.lib.mpc_stream_concurrency(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
@@ -326,6 +354,7 @@ class BatchedMPC:
         _lib.check(self.lib.mpc_set_profile(self._h, int(bool(on))))
 
     def last_solve_info(self):
+        self._free()
         r, g, c = C.c_int64(), C.c_int64(), C.c_int64()
         e, s = C.c_double(), C.c_double()
         _lib.check(self.lib.mpc_last_solve_info(self._h, C.byref(r), C.byref(g), C.byref(c),

@@ -466,6 +466,7 @@ typedef struct {
     int n, m;
     long n_evals; /* psi/grad evaluations (statistics) */
     int in_ls;    /* diagnostics: inside a line-search trial */
+    int outer, base_iters; /* diagnostics: ALM outer iteration, inner iterations of the earlier inner solves */
 } prob_t;
 
 static double dot(const double *a, const double *b, int n)
@@ -565,6 +566,16 @@ typedef struct { int status; int iters; double eps; double psi_hat; int wrote; }
 static __thread double g_lsc[8];
 void orc_last_ls_counters(double *out) { memcpy(out, g_lsc, sizeof g_lsc); }
 
+/* optional per-INNER-iteration trace (orc_solve_itertrace; study aid of the HIP-vs-oracle divergence diagnosis,
+ * tools/dev/first_divergence.py): one row of ORC_ITRACE_COLS doubles per accepted iteration, holding the state
+ * the iteration leaves and, for every comparison that steers the algorithm, the smallest margin by which it
+ * was decided in this iteration -- a margin at rounding level is a decision another correct implementation
+ * may take the other way. */
+static __thread double *g_it = NULL;
+static __thread int g_it_rows = 0, g_it_n = 0;
+static __thread double g_it_dl, g_it_ls, g_it_act, g_it_heur;
+static void it_min(double *slot, double v) { v = fabs(v); if (v < *slot) *slot = v; }
+
 static double eval_psi(prob_t *P, const double *x, const double *y, const double *Sig, double *grad,
                        double *yhat)
 {
@@ -580,7 +591,9 @@ static void descent_lemma(prob_t *P, const double *y, const double *Sig, const d
     const orc_config *c = P->c;
     double margin = (1.0 + fabs(psik)) * c->qub_tol;
     int run = 0;
-    while (*psixh - psik > *gp + 0.5 * (*L) * (*pp) + margin) {
+    for (;;) {
+        if (g_it) it_min(&g_it_dl, ((*psixh - psik) - (*gp + 0.5 * (*L) * (*pp) + margin)) / (1.0 + fabs(psik)));
+        if (!(*psixh - psik > *gp + 0.5 * (*L) * (*pp) + margin)) break;
         if (!((*L) * 2.0 <= c->L_max)) break;
         g_lsc[P->in_ls ? 2 : 3] += 1; if (++run > g_lsc[4]) g_lsc[4] = run;
         *L *= 2.0; *gamma /= 2.0;
@@ -649,6 +662,7 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
             hess_prod_fd(P, y, Sig, xk, gk, gk, HqK, work);
             double gHg = dot(gk, HqK, n), gg = dot(gk, gk, n);
             double eta = gg / gHg;
+            if (g_it) it_min(&g_it_heur, (eta * c->Lgamma_factor - gamma) / gamma);
             if (eta > 0 && isfinite(eta) && eta * c->Lgamma_factor > gamma) {
                 Lk = 1.0 / eta;
                 gamma = c->Lgamma_factor / Lk;
@@ -666,6 +680,8 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
 
         /* stop criterion ProjGradNorm2 (controller.py:29): ||p|| / gamma */
         double epsk = sqrt(pp) / gamma;
+        /* the stop test ON the iterate the previous row describes (same inner solve: k > 0) */
+        if (g_it && k > 0 && g_it_n > 0 && g_it_n <= g_it_rows) g_it[(size_t)(g_it_n - 1) * ORC_ITRACE_COLS + 18] = epsk / eps - 1.0;
         int stop = epsk <= eps ? ORC_ST_CONVERGED
                  : (c->max_total_evals > 0 && P->n_evals >= c->max_total_evals) ? ORC_ST_MAXTIME
                  : k == max_iter ? ORC_ST_MAXITER
@@ -699,6 +715,7 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
             for (int i = 0; i < n; i++) {
                 double lbi = c->u_lb[i & 1], ubi = c->u_ub[i & 1];
                 double gd = xk[i] - gamma * gk[i];
+                if (g_it) { it_min(&g_it_act, gd - lbi); it_min(&g_it_act, ubi - gd); }
                 if (gd < lbi || ubi < gd) { q[i] = p[i]; mask[i] = 0.0; }
                 else { q[i] = 0.0; mask[i] = 1.0; nJ++; }
             }
@@ -728,8 +745,10 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
         double phin, psin, psixhn, gpn, ppn, Ln, gamman, ls_cond;
         g_lsc[1] += 1; P->in_ls = 1;
         int it_trials = 0; double qub_before = g_lsc[2];
+        double tau_used = tau; int safe_step = 0;
         do {
             g_lsc[0] += 1; it_trials++;
+            tau_used = tau; safe_step = tau / 2.0 < c->tau_min;
             Ln = Lk; gamman = gamma;
             if (tau / 2.0 < c->tau_min) {
                 g_lsc[6] += 1;
@@ -748,6 +767,7 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
             descent_lemma(P, y, Sig, xn, psin, gn, xhn, pn, yhxn, &psixhn, &ppn, &gpn, &Ln, &gamman);
             phin = psin + ppn / (2.0 * gamman) + gpn;
             ls_cond = phin - (phik - sig_pp);
+            if (g_it) it_min(&g_it_ls, (ls_cond - margin) / (1.0 + fabs(phik)));
             tau /= 2.0;
             /* a NaN condition (the trial point's evaluation overflowed) is a failed trial, like +inf:
              * alpaqa's literal `ls_cond > margin` would accept it because NaN compares false */
@@ -759,7 +779,7 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
         g_lsc[7] += (it_trials + 3) / 4 + (it_trials + 1) / 2 + (g_lsc[2] - qub_before);
 
         if (gamma != gamman) lbfgs_reset(lb);
-        lbfgs_update(lb, xk, xn, gk, gn);
+        const int pair_ok = lbfgs_update(lb, xk, xn, gk, gn);
 
         if (no_progress > 0 || k % c->max_no_progress == 0) {
             int same = 1;
@@ -774,6 +794,20 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
         memcpy(gk, gn, n * sizeof(double));
         if (m) memcpy(yhx, yhxn, m * sizeof(double));
         gp = gpn; pp = ppn;
+        if (g_it) {
+            if (g_it_n < g_it_rows) {
+                double *t = g_it + (size_t)g_it_n * ORC_ITRACE_COLS;
+                /* tau of the accepted trial (the HIP record holds it halved, as `tau` is here by now); the safe prox
+                 * step x+ = xhat is reported as its negative */
+                t[0] = P->base_iters + k + 1; t[1] = P->outer; t[2] = k + 1; t[3] = eps;
+                t[4] = safe_step ? -tau_used : tau_used;
+                t[5] = it_trials; t[6] = Lk; t[7] = gamma; t[8] = nJ; t[9] = lb->full ? lb->M : lb->idx;
+                t[10] = pair_ok; t[11] = psik; t[12] = phik; t[13] = pp; t[14] = (double)P->n_evals;
+                t[15] = g_it_ls; t[16] = g_it_dl; t[17] = g_it_act; t[18] = NAN; t[19] = g_it_heur;
+            }
+            g_it_n++;
+            g_it_ls = g_it_dl = g_it_act = g_it_heur = INFINITY;
+        }
     }
     st.status = ORC_ST_MAXITER; st.iters = max_iter;
     return st;
@@ -813,10 +847,20 @@ int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, do
     return g_trace_n;
 }
 
+int orc_solve_itertrace(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
+                        double *stats, double *trace, int max_rows)
+{
+    g_it = trace; g_it_rows = max_rows; g_it_n = 0;
+    g_it_ls = g_it_dl = g_it_act = g_it_heur = INFINITY;
+    orc_solve(c, x0, cl, U, lam, stats);
+    g_it = NULL;
+    return g_it_n;
+}
+
 void orc_solve(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                double *stats)
 {
-    prob_t P = {c, x0, cl, 2 * c->N, orc_m(c), 0, 0};
+    prob_t P = {c, x0, cl, 2 * c->N, orc_m(c), 0, 0, 0, 0};
     memset(g_lsc, 0, sizeof g_lsc);
     const int n = P.n, m = P.m, mm = m ? m : 1;
     const int M = c->lbfgs_memory;
@@ -853,6 +897,7 @@ void orc_solve(const orc_config *c, const double *x0, const double *cl, double *
         /* the last inner solve the budget allows always hands back its iterate */
         int last_by_budget = max_it >= budget;
         int overwrite = out_of_iter || out_of_pen || last_by_budget;
+        P.outer = i; P.base_iters = inner_it;
         inner_stats ps = panoc(&P, Sig, eps, overwrite, max_it, U, lam, e2, wk, &lb);
         int conv = ps.status == ORC_ST_CONVERGED;
         if (ps.wrote) out_psi = ps.psi_hat;

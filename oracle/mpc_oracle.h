@@ -106,6 +106,18 @@ void orc_solve(const orc_config *c, const double *x0, const double *cl,
 int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                      double *stats, double *trace, int max_rows);
 
+/* the same, recording one row per accepted INNER iteration into trace[max_rows][ORC_ITRACE_COLS] (study aid of
+ * the HIP-vs-oracle first-divergence diagnosis): [inner iterations so far (over all inner solves), ALM outer
+ * iteration, iteration of this inner solve, eps asked, tau of the accepted trial (negative: the safe prox step),
+ * line-search trials, L, gamma, |J|, L-BFGS pairs held, pair accepted, psi, phi_gamma, ||p||^2, evaluations so
+ * far, and the smallest margin by which this iteration decided its line-search tests / descent-lemma tests /
+ * active-set memberships (absolute) / the stop test ON the iterate it produced (eps_k / eps - 1; NaN when that
+ * test belongs to the next inner solve) / the step-size heuristic];
+ * returns the number of iterations (rows beyond max_rows are not written) */
+#define ORC_ITRACE_COLS 20
+int orc_solve_itertrace(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
+                        double *stats, double *trace, int max_rows);
+
 /* batch: x0 [B][nx], cl table [C][2S], cl_index [B] (NULL -> all 0), U [B][n], lam [B][m] */
 void orc_solve_batch(const orc_config *c, int B, const double *x0, const double *cl,
                      const int32_t *cl_index, double *U, double *lam, double *stats,

@@ -76,6 +76,7 @@ def lib():
         L.orc_psi.argtypes = [cp, dp, dp, dp, dp, dp, dp, dp]; L.orc_psi.restype = C.c_double
         L.orc_solve.argtypes = [cp, dp, dp, dp, dp, dp]
         L.orc_solve_traced.argtypes = [cp, dp, dp, dp, dp, dp, dp, C.c_int]; L.orc_solve_traced.restype = C.c_int
+        L.orc_solve_itertrace.argtypes = [cp, dp, dp, dp, dp, dp, dp, C.c_int]; L.orc_solve_itertrace.restype = C.c_int
         L.orc_solve_batch.argtypes = [cp, C.c_int, dp, dp, ip, dp, dp, dp, C.c_int]
         L.orc_psi_batch.argtypes = [cp, C.c_int, dp, dp, ip, dp, dp, dp, dp, dp, C.c_int]
         L.orc_max_threads.restype = C.c_int
@@ -195,6 +196,23 @@ def solve_traced(cfg, x0, cl, U0, lam0=None, max_rows=256):
     tr = np.zeros((max_rows, len(TRACE_COLS)))
     k = lib().orc_solve_traced(C.byref(cfg), _d(x0), _d(cl), _d(U), _d(lam), _d(st), _d(tr), max_rows)
     return U, lam[:mm], st, tr[:k]
+
+
+ITRACE_COLS = ["inner_total", "outer", "k", "eps_asked", "tau", "trials", "L", "gamma", "nJ", "lbfgs_pairs",
+               "pair_ok", "psi", "phi", "pp", "evals", "margin_ls", "margin_dl", "margin_active", "margin_stop",
+               "margin_heur"]
+
+
+def solve_itertrace(cfg, x0, cl, U0, lam0=None, max_rows=6000):
+    """solve() plus one trace row per accepted inner iteration (columns: ITRACE_COLS; mpc_oracle.h)."""
+    x0, cl = _f64(x0), _f64(cl)
+    U = _f64(U0).copy()
+    mm = m(cfg)
+    lam = np.zeros(max(mm, 1)) if lam0 is None else _f64(lam0).copy()
+    st = np.empty(NSTATS)
+    tr = np.zeros((max_rows, len(ITRACE_COLS)))
+    k = lib().orc_solve_itertrace(C.byref(cfg), _d(x0), _d(cl), _d(U), _d(lam), _d(st), _d(tr), max_rows)
+    return U, lam[:mm], st, tr[:min(k, max_rows)]
 
 
 def solve_batch(cfg, x0, cl, U0, lam0=None, cl_index=None, nthreads=0):

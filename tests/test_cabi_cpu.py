@@ -132,3 +132,12 @@ def test_product_package_never_imports_the_oracle():
     code = ("import sys; sys.path.insert(0, %r); import model_predictive_control_amd; "
             "assert not any('oracle' in m for m in sys.modules), 'oracle imported'" % ROOT)
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_debug_record_names_follow_the_record_layout(L):
+    """mpc_debug_record_names(): one name per slot in use of the per-agent solver record (static_assert in
+    mpc_api.hip ties the count to the enum), no duplicates, within MPC_NREC."""
+    names = L.mpc_debug_record_names().decode().split(",")
+    assert len(names) == len(set(names)) == 62 and len(names) <= _lib.NREC
+    for must in ("L", "gamma", "tau", "nJ", "lidx", "lfull", "nevals", "k", "outer", "fallback", "phase"):
+        assert must in names

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU path's host logic: contiguous sharding of the agent
+"""gloo tests (world_size 2 and 8) of the multi-GPU path's host logic: contiguous sharding of the agent
 batch, independent per-rank work, and the final gather of the controls (the only collective)."""
 import os
 import socket
@@ -90,6 +90,47 @@ def test_gather_ragged_shards(tmp_path):
 
 def test_gather_with_empty_shard(tmp_path):
     _run(1, 3, tmp_path)
+
+
+def _config4_worker(rank, world, port, B, k, out_dir):
+    """BASELINE config 4's row counts on eight ranks: every rank builds its shard as a pure function of the
+    global agent index (what bench.py's generator guarantees), rank 0 gathers and checks the rows in place --
+    524 288 x k doubles are 16 MB at k = 4, so nothing is written to disk but the verdict."""
+    sys.path.insert(0, ROOT)
+    from model_predictive_control_amd.sharding import gather_controls, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(B, rank, world)
+    idx = torch.arange(lo, hi, dtype=torch.float64)
+    local = torch.stack([idx * 8 + j for j in range(k)], 1)
+    full = gather_controls(local, B, dst=0)
+    ok = True
+    if rank == 0:
+        expect = torch.stack([torch.arange(B, dtype=torch.float64) * 8 + j for j in range(k)], 1)
+        ok = full.shape == (B, k) and torch.equal(full, expect)
+    else:
+        ok = full is None
+    # shards tile [0, B) in rank order, sizes differ by at most one
+    bounds = [shard_bounds(B, r, world) for r in range(world)]
+    ok = ok and bounds[0][0] == 0 and bounds[-1][1] == B and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    ok = ok and max(h - l for l, h in bounds) - min(h - l for l, h in bounds) <= 1
+    dist.barrier()
+    with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+        f.write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_at_config4_row_counts(tmp_path):
+    """BASELINE config 4: 524 288 agents sharded over 8 ranks (65 536 each), and a ragged total that no rank count
+    divides -- shard_bounds / gather_controls with world_size 8 (gloo on the CPU; the 8-GPU run is the driver's)."""
+    for sub, B in (("even", 524288), ("ragged", 524288 - 8 * 3 + 5)):
+        d = tmp_path / sub
+        d.mkdir()
+        port = _free_port()
+        mp.spawn(_config4_worker, args=(8, port, B, 4, str(d)), nprocs=8, join=True)
+        for r in range(8):
+            assert (d / f"ok{r}").read_text() == "ok", (sub, r)
 
 
 def _probe_worker(rank, world, port, out_dir):

@@ -1,4 +1,5 @@
 """CPU tests of the host-side mirror of the reference interface (no kernels are launched)."""
+import os
 import numpy as np
 import pytest
 
@@ -126,15 +127,27 @@ def test_thread_serial_tree_sum_has_the_bits_of_the_wave_reduction():
     assert differs_from_sequential > 100          # (the test can tell orders apart)
 
 
-def test_bench_reads_the_newest_counter_summary(tmp_path, monkeypatch):
-    """bench.py's `roofline.traffic` comes from the newest profiles/r*_pmc_summary.json; the tags run r03a .. r03z,
-    r03aa ..., so "newest" is shorter-names-first, then alphabetical (a plain sort put r03w after r03aw)."""
-    import json
+def test_bench_uses_only_a_counter_summary_of_the_running_build(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from a committed rocprofv3 counter summary -- only from one taken on the
+    RUNNING library (its `library_source_sha256` = mpc_source_hash, which _lib.build() compiles in): counters of an
+    older build are another kernel's traffic, and the line then carries `traffic: null` (a stale summary
+    passed the workload-string guard).  Among matching summaries the most recent file wins."""
+    import json as _json
+    import time as _time
     import bench
+    from model_predictive_control_amd import _lib
+    mine = _lib.library_hash()
+    assert mine == _lib.source_hash() and len(mine) == 64         # the library in the tree is built from the tree
     prof = tmp_path / "profiles"
     prof.mkdir()
-    for tag in ("r02e", "r03h", "r03w", "r03am", "r03aw"):
-        (prof / (tag + "_pmc_summary.json")).write_text(json.dumps({"tag": tag}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    pmc, src = bench.pmc_profile()
-    assert pmc["tag"] == "r03aw" and src.endswith("r03aw_pmc_summary.json")
+    assert bench.pmc_profile() == (None, None)                    # nothing committed
+    (prof / "r09z_pmc_summary.json").write_text(_json.dumps({"library_source_sha256": "0" * 64, "hbm_bytes_per_solve": 1.0}))
+    (prof / "r09y_pmc_summary.json").write_text(_json.dumps({"hbm_bytes_per_solve": 2.0}))          # no hash at all
+    assert bench.pmc_profile() == (None, None)                    # another build's counters are not used
+    (prof / "r04a_pmc_summary.json").write_text(_json.dumps({"library_source_sha256": mine, "hbm_bytes_per_solve": 3.0}))
+    d, src = bench.pmc_profile()
+    assert d["hbm_bytes_per_solve"] == 3.0 and src == os.path.join("profiles", "r04a_pmc_summary.json")
+    _time.sleep(0.05)
+    (prof / "r04b_pmc_summary.json").write_text(_json.dumps({"library_source_sha256": mine, "hbm_bytes_per_solve": 4.0}))
+    assert bench.pmc_profile()[0]["hbm_bytes_per_solve"] == 4.0
