@@ -76,7 +76,9 @@ struct mpc_handle {
     char *arena = nullptr; // one device allocation carved into the Workspace arrays
     size_t arena_bytes = 0;
     Workspace ws{};
-    int *host_counts = nullptr; // pinned: [2 poll windows][MPC_MAX_GROUPS][2]
+    int *host_counts = nullptr; // pinned, 512 B: [2 poll windows][MPC_MAX_GROUPS][2] ints, then (byte 128) the eight totals of a
+                                // solve and (byte 192) the persistent kernel's counters -- copies into pageable memory would
+                                // block the host until the stream has drained, whatever the wall-clock bound says
     hipEvent_t pollev[2][MPC_MAX_GROUPS] = {{nullptr}};
     hipEvent_t soloev[MPC_MAX_GROUPS][2] = {{nullptr}}; // profile mode: around a group's persistent-kernel launch
     // profiling of the last solve
@@ -323,7 +325,7 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;
     }
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_counts, 256, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->host_counts, 512, hipHostMallocDefault);
     if (e != hipSuccess) { delete h; return fail(MPC_E_HIP, std::string("mpc_create: ") + hipGetErrorString(e)); }
     const char *p = getenv("MPC_PROFILE");
     h->profile = p && p[0] == '1';
@@ -1146,11 +1148,12 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     }
     for (int g = 0; g < ng; g++) h->rounds = std::max<int64_t>(h->rounds, rounds_done[g]);
     {
-        unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int sctr[2 * MPC_MAX_GROUPS];
+        unsigned long long *tot = (unsigned long long *)((char *)h->host_counts + 128);   // pinned (see host_counts)
+        int *sctr = (int *)((char *)h->host_counts + 192);
+        static_assert(8 * sizeof(unsigned long long) == 64 && 2 * MPC_MAX_GROUPS * sizeof(int) == 64, "pinned staging layout");
         hipLaunchKernelGGL(totals_kernel, grid_for(B, 256), dim3(256), 0, s, w);
-        HIPCHK(hipMemcpyAsync(tot, w.totals, sizeof tot, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(sctr, w.solo_ctr, sizeof sctr, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tot, w.totals, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sctr, w.solo_ctr, 2 * MPC_MAX_GROUPS * sizeof(int), hipMemcpyDeviceToHost, s));
         { const int rs = bounded_sync(h, s, "mpc_solve_batch"); if (rs) return rs; }
         h->evals_grad = (int64_t)tot[0]; h->evals_cost = (int64_t)tot[1]; h->lbfgs_rows = (int64_t)tot[2];
         h->spec_issued = (int64_t)tot[4]; h->spec_used = (int64_t)tot[5];

@@ -467,6 +467,7 @@ typedef struct {
     long n_evals; /* psi/grad evaluations (statistics) */
     int in_ls;    /* diagnostics: inside a line-search trial */
     int outer, base_iters; /* diagnostics: ALM outer iteration, inner iterations of the earlier inner solves */
+    uint64_t jit;          /* evaluation jitter (orc_set_eval_jitter): generator state, 0 = off */
 } prob_t;
 
 static double dot(const double *a, const double *b, int n)
@@ -576,11 +577,41 @@ static __thread int g_it_rows = 0, g_it_n = 0;
 static __thread double g_it_dl, g_it_ls, g_it_act, g_it_heur;
 static void it_min(double *slot, double v) { v = fabs(v); if (v < *slot) *slot = v; }
 
+/* Study aid (orc_set_eval_jitter): every psi and every gradient component the solver sees is moved by a random
+ * whole number of ulps in [-ulps, ulps] -- what ANOTHER correct implementation of the same formulae (other
+ * summation order, other libm, fused multiply-adds) would hand the same algorithm.  Used to measure how far the
+ * solver's path and end point depend on the last bits of its evaluations: the yardstick the HIP-vs-oracle
+ * agreement is held against (tests/test_oracle_golden.py, tests/test_gpu_parity.py).  Process-wide, off by default. */
+static int g_jitter_ulps = 0;
+static uint64_t g_jitter_seed = 0;
+void orc_set_eval_jitter(int ulps, uint64_t seed) { g_jitter_ulps = ulps < 0 ? 0 : ulps; g_jitter_seed = seed; }
+static double jitter(prob_t *P, double v)
+{
+    P->jit = P->jit * 6364136223846793005ULL + 1442695040888963407ULL;
+    const int k = (int)((P->jit >> 33) % (uint64_t)(2 * g_jitter_ulps + 1)) - g_jitter_ulps;
+    if (k == 0 || !isfinite(v) || v == 0.0) return v;
+    int64_t b; memcpy(&b, &v, 8); b += k; memcpy(&v, &b, 8);   /* k ulps along the number line of |v| */
+    return v;
+}
+
+/* study aid (orc_solve_dump_evals): every point evaluated during ONE inner iteration, with the value returned */
+static __thread double *g_dump = NULL;
+static __thread int g_dump_rows = 0, g_dump_n = 0, g_dump_iter = -1, g_dump_on = 0;
+
 static double eval_psi(prob_t *P, const double *x, const double *y, const double *Sig, double *grad,
                        double *yhat)
 {
     P->n_evals++;
-    return orc_psi(P->c, P->x0, P->cl, x, y, Sig, grad, yhat);
+    double v = orc_psi(P->c, P->x0, P->cl, x, y, Sig, grad, yhat);
+    if (g_dump_on && g_dump_n < g_dump_rows) {
+        double *t = g_dump + (size_t)g_dump_n++ * (P->n + 2);
+        t[0] = grad ? 1.0 : 0.0; t[1] = v; memcpy(t + 2, x, P->n * sizeof(double));
+    }
+    if (P->jit) {
+        v = jitter(P, v);
+        if (grad) for (int i = 0; i < P->n; i++) grad[i] = jitter(P, grad[i]);
+    }
+    return v;
 }
 
 /* alpaqa detail::descent_lemma */
@@ -654,6 +685,7 @@ static inner_stats panoc(prob_t *P, const double *Sig, double eps, int always_ov
     double phik = psik + pp / (2.0 * gamma) + gp;
 
     for (int k = 0; k <= max_iter; k++) {
+        g_dump_on = g_dump != NULL && P->base_iters + k + 1 == g_dump_iter;
         int gamma_changed_top = 0;
         double gamma_old_top = gamma;
         /* hessian_step_size_heuristic (controller.py:32) [RECALLED, safeguarded]:
@@ -847,6 +879,15 @@ int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, do
     return g_trace_n;
 }
 
+int orc_solve_dump_evals(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
+                         double *stats, int iteration, double *out, int max_rows)
+{
+    g_dump = out; g_dump_rows = max_rows; g_dump_n = 0; g_dump_iter = iteration; g_dump_on = 0;
+    orc_solve(c, x0, cl, U, lam, stats);
+    g_dump = NULL; g_dump_on = 0;
+    return g_dump_n;
+}
+
 int orc_solve_itertrace(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                         double *stats, double *trace, int max_rows)
 {
@@ -860,7 +901,13 @@ int orc_solve_itertrace(const orc_config *c, const double *x0, const double *cl,
 void orc_solve(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                double *stats)
 {
-    prob_t P = {c, x0, cl, 2 * c->N, orc_m(c), 0, 0, 0, 0};
+    prob_t P = {c, x0, cl, 2 * c->N, orc_m(c), 0, 0, 0, 0, 0};
+    if (g_jitter_ulps > 0) {   /* a generator per solve, keyed by the agent's initial state: the same jitter whatever the thread */
+        uint64_t k0; memcpy(&k0, &x0[0], 8);
+        uint64_t k1; memcpy(&k1, &x0[1], 8);
+        P.jit = (k0 * 0x9E3779B97F4A7C15ULL) ^ (k1 + g_jitter_seed * 0xD1B54A32D192ED03ULL) ^ 0x2545F4914F6CDD1DULL;
+        if (P.jit == 0) P.jit = 1;
+    }
     memset(g_lsc, 0, sizeof g_lsc);
     const int n = P.n, m = P.m, mm = m ? m : 1;
     const int M = c->lbfgs_memory;

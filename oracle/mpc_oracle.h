@@ -118,6 +118,19 @@ int orc_solve_traced(const orc_config *c, const double *x0, const double *cl, do
 int orc_solve_itertrace(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
                         double *stats, double *trace, int max_rows);
 
+/* study aid: the solve of one agent, recording every evaluation made during inner iteration `iteration` (counted
+ * over all inner solves, from 1) into out[max_rows][n + 2] = [1 gradient / 0 cost only, psi returned, the point];
+ * returns the number of rows */
+int orc_solve_dump_evals(const orc_config *c, const double *x0, const double *cl, double *U, double *lam,
+                         double *stats, int iteration, double *out, int max_rows);
+
+/* study aid: from now on every psi value and gradient component the SOLVER sees (orc_solve*, not orc_psi*) is moved
+ * by a random whole number of ulps in [-ulps, ulps] (generator keyed by the agent's initial state and `seed`); 0 = off
+ * (default).  Models another correct implementation of the same formulae: the yardstick for HIP-vs-oracle agreement
+ * of solver PATHS, which depend on the last bits of the evaluations (finite-difference Hessian-vector products
+ * divide gradient differences by h ~ 3e-5).  Process-wide; not thread-safe against running solves. */
+void orc_set_eval_jitter(int ulps, uint64_t seed);
+
 /* batch: x0 [B][nx], cl table [C][2S], cl_index [B] (NULL -> all 0), U [B][n], lam [B][m] */
 void orc_solve_batch(const orc_config *c, int B, const double *x0, const double *cl,
                      const int32_t *cl_index, double *U, double *lam, double *stats,

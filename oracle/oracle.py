@@ -77,6 +77,8 @@ def lib():
         L.orc_solve.argtypes = [cp, dp, dp, dp, dp, dp]
         L.orc_solve_traced.argtypes = [cp, dp, dp, dp, dp, dp, dp, C.c_int]; L.orc_solve_traced.restype = C.c_int
         L.orc_solve_itertrace.argtypes = [cp, dp, dp, dp, dp, dp, dp, C.c_int]; L.orc_solve_itertrace.restype = C.c_int
+        L.orc_solve_dump_evals.argtypes = [cp, dp, dp, dp, dp, dp, C.c_int, dp, C.c_int]; L.orc_solve_dump_evals.restype = C.c_int
+        L.orc_set_eval_jitter.argtypes = [C.c_int, C.c_uint64]
         L.orc_solve_batch.argtypes = [cp, C.c_int, dp, dp, ip, dp, dp, dp, C.c_int]
         L.orc_psi_batch.argtypes = [cp, C.c_int, dp, dp, ip, dp, dp, dp, dp, dp, C.c_int]
         L.orc_max_threads.restype = C.c_int
@@ -213,6 +215,32 @@ def solve_itertrace(cfg, x0, cl, U0, lam0=None, max_rows=6000):
     tr = np.zeros((max_rows, len(ITRACE_COLS)))
     k = lib().orc_solve_itertrace(C.byref(cfg), _d(x0), _d(cl), _d(U), _d(lam), _d(st), _d(tr), max_rows)
     return U, lam[:mm], st, tr[:min(k, max_rows)]
+
+
+def solve_dump_evals(cfg, x0, cl, U0, iteration, max_rows=512):
+    """Every evaluation the solve makes during inner iteration `iteration`: rows [is_gradient, psi, point...]."""
+    x0, cl = _f64(x0), _f64(cl)
+    U = _f64(U0).copy()
+    lam = np.zeros(max(m(cfg), 1))
+    st = np.empty(NSTATS)
+    n = 2 * cfg.N
+    out = np.zeros((max_rows, n + 2))
+    k = lib().orc_solve_dump_evals(C.byref(cfg), _d(x0), _d(cl), _d(U), _d(lam), _d(st), int(iteration), _d(out), max_rows)
+    return out[:k]
+
+
+class eval_jitter:
+    """`with eval_jitter(ulps, seed):` -- solves inside see every psi / gradient component moved by a random whole
+    number of ulps in [-ulps, ulps] (mpc_oracle.h orc_set_eval_jitter): another correct implementation's evaluations."""
+
+    def __init__(self, ulps, seed=0):
+        self.ulps, self.seed = int(ulps), int(seed)
+
+    def __enter__(self):
+        lib().orc_set_eval_jitter(self.ulps, self.seed)
+
+    def __exit__(self, *exc):
+        lib().orc_set_eval_jitter(0, 0)
 
 
 def solve_batch(cfg, x0, cl, U0, lam0=None, cl_index=None, nthreads=0):

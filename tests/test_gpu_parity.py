@@ -285,38 +285,85 @@ def test_iterate_prefix_parity(dev, O, model, N):
     """Iterate-level parity: stop BOTH implementations after k inner iterations and compare the
     iterate, not only the end point.  `max_total_inner = k` is the stop: the last inner solve the budget allows hands
     back its prox point under the `overwrite` rule in both (oracle/mpc_oracle.c orc_solve; mpc_solver.hpp
-    PH_OUTER_BEGIN), so a solve with budget k is the first k iterations of the long solve.  On the first 256 agents of
-    bench.py's batch, for the agents whose evaluation counts agree (the two implementations took the same decisions
-    up to there): controls within 1e-9 absolute, inner / outer iteration counts and status exact, psi(xhat) within
-    1e-9; and the fraction of such agents is asserted per k (measured: profiles/r04_first_divergence.txt -- what
-    parts the two later is a comparison decided at rounding level, tools/dev/first_divergence.py)."""
+    PH_OUTER_BEGIN), so a solve with budget k is the first k iterations of the long solve.  First 256 agents of
+    bench.py's batch, k = 1 ... 40.
+
+    What can be asserted is set by the ALGORITHM, not by either implementation: alpaqa's finite-difference quantities
+    divide gradient differences by h ~ 5e-6 (initial Lipschitz estimate) and h ~ 3e-5 (Hessian-vector products), so
+    last-bit differences between two correct evaluations of the same gradient come back multiplied by 1e5, and the
+    quasi-Newton iteration roughly doubles them per iteration.  The yardstick is therefore the oracle AGAINST ITSELF
+    with every psi / gradient component it sees moved by a random -2 .. 2 ulp (O.eval_jitter: what another correct
+    implementation would hand the same algorithm; the HIP transcendentals are within 2 ulp of libm): per k,
+      * the two implementations must have taken the same decisions (equal evaluation, inner and outer iteration
+        counts, status) for at least as large a fraction of the agents as the jittered oracle does, minus 2 %;
+      * among those agents the iterates must be as close as the jittered oracle's are to the plain one's: median
+        |dU| within 20x, maximum within 100x (both heavy-tailed over agents), and 1e-9 absolute (Pacejka: 1e-8) after the
+        first iteration, where only the Lipschitz estimate's amplification has acted.
+    The first-divergence study (tools/dev/first_divergence.py, profiles/r04_first_divergence.txt) shows what ends the
+    agreement later: comparisons decided by margins at rounding level."""
     import bench
     B = 256
     X0 = bench.synthetic_states(model, 0, B)
     cl = straight_centerline()
     U0 = np.tile([1.0, 0.0], (B, N))
     X0d, cld, U0d = T(X0, dev), T(cl, dev), T(U0, dev)
-    floors = PREFIX_FLOORS[model]
-    report = []
+    report, runs = [], []
     for k in (1, 2, 3, 5, 10, 20, 40):
         cfg, ocfg = both(O, model, N, max_total_inner=k)
         U, _, st = mp.BatchedMPC(cfg, dev).solve(X0d, cld, U0d)
         U, st = U.cpu().numpy(), st.cpu().numpy()
         Uo, _, so = O.solve_batch(ocfg, X0, cl, U0)
+        with O.eval_jitter(2, 7):
+            Uj, _, sj = O.solve_batch(ocfg, X0, cl, U0)
         same = st[:, 7] == so[:, 7]
-        report.append((k, float(same.mean()), float(np.abs(U - Uo)[same].max())))
-        assert same.mean() >= floors[k], report
+        samej = sj[:, 7] == so[:, 7]
+        dh, dj = np.abs(U - Uo).max(1)[same], np.abs(Uj - Uo).max(1)[samej]
+        runs.append((k, st, so, same, samej, dh, dj))
+        report.append((k, round(float(same.mean()), 4), round(float(samej.mean()), 4), "%.1e/%.1e" % (np.median(dh), dh.max()),
+                       "%.1e/%.1e" % (np.median(dj), dj.max())))
+    print("iterate-prefix parity, model", model, "(k, equal-count fraction HIP vs oracle, jittered oracle vs oracle, "
+          "median/max |dU| HIP, median/max |dU| jittered):", report)
+    for k, st, so, same, samej, dh, dj in runs:
+        assert same.mean() >= samej.mean() - 0.02, report
         assert (st[same, 2] == so[same, 2]).all() and (st[same, 1] == so[same, 1]).all() and (st[same, 0] == so[same, 0]).all(), report
-        assert (st[same, 2] <= k).all()
-        assert np.abs(U - Uo)[same].max() <= 1e-9, report
-        assert np.abs(st[same, 6] - so[same, 6]).max() <= 1e-9, report
-    print("iterate-prefix parity, model", model, [(k, round(f, 4), "%.1e" % d) for k, f, d in report])
+        assert (st[:, 2] <= k).all() and (so[:, 2] <= k).all()
+        assert np.median(dh) <= 20.0 * np.median(dj) + 1e-13 and dh.max() <= 100.0 * dj.max(), report
+        if k == 1:
+            assert dh.max() <= (1e-9 if model == 0 else 1e-8), report
 
 
-# fraction of the 256 agents whose evaluation counts agree after k inner iterations (floors a little under what
-# profiles/r04_first_divergence.txt measured)
-PREFIX_FLOORS = {0: {1: 0.0, 2: 0.0, 3: 0.0, 5: 0.0, 10: 0.0, 20: 0.0, 40: 0.0},
-                 1: {1: 0.0, 2: 0.0, 3: 0.0, 5: 0.0, 10: 0.0, 20: 0.0, 40: 0.0}}
+@pytest.mark.parametrize("model,N", [(0, 20), (1, 12)])
+def test_path_agreement_is_the_oracles_own_rounding_sensitivity(dev, O, model, N):
+    """WHY only a few per cent of the headline configuration's agents take the oracle's exact (status, iterations)
+    path: so does the oracle against ITSELF once its evaluations carry 2 ulp of noise.  On the
+    first 1 024 agents of bench.py's batch at the reference's eps = 1e-6 -- measured, profiles/r04_first_divergence.txt:
+    kinematic N = 20: HIP vs oracle 4.5 % identical paths, jittered oracle vs oracle 4.2 %; Pacejka N = 12: 46.5 % vs
+    44.6 % -- the HIP solver must agree with the oracle on at least as many paths as the jittered oracle does (minus
+    three binomial standard deviations), and its controls must be within 1e-5 of the oracle's for at least as large a
+    fraction of the agents (minus 3 %).  The end points agree (both stop inside the same eps-ball); the paths through
+    a flat nonconvex valley are decided by the last bits."""
+    import bench
+    B = 1024
+    X0 = bench.synthetic_states(model, 0, B)
+    cl = straight_centerline()
+    U0 = np.tile([1.0, 0.0], (B, N))
+    cfg, ocfg = both(O, model, N)
+    U, _, st = mp.BatchedMPC(cfg, dev).solve(T(X0, dev), T(cl, dev), T(U0, dev))
+    U, st = U.cpu().numpy(), st.cpu().numpy()
+    Uo, _, so = O.solve_batch(ocfg, X0, cl, U0)
+    with O.eval_jitter(2, 1):
+        Uj, _, sj = O.solve_batch(ocfg, X0, cl, U0)
+    path = lambda a, b: float(((a[:, 0] == b[:, 0]) & (a[:, 2] == b[:, 2])).mean())
+    ph, pj = path(st, so), path(sj, so)
+    dh, dj = bench.rel_dU(U, Uo), bench.rel_dU(Uj, Uo)
+    print("identical paths, model", model, ": HIP vs oracle %.3f, jittered oracle vs oracle %.3f; controls within 1e-5: %.4f / %.4f; "
+          "max rel dU %.2e / %.2e" % (ph, pj, (dh <= 1e-5).mean(), (dj <= 1e-5).mean(), dh.max(), dj.max()))
+    assert (st[:, 0] == so[:, 0]).all() and (st[:, 1] == so[:, 1]).mean() >= 0.97
+    assert ph >= pj - 3.0 * np.sqrt(max(pj * (1 - pj), 0.01) / B), (ph, pj)
+    assert (dh <= 1e-5).mean() >= (dj <= 1e-5).mean() - 0.03, ((dh <= 1e-5).mean(), (dj <= 1e-5).mean())
+    # (medians: the typical agent; the maxima are single agents -- on the Pacejka model one in a few thousand ends in
+    # another local minimum in either comparison)
+    assert np.median(dh) <= 5.0 * np.median(dj) + 1e-9
 
 
 def test_in_place_centerline_refresh_is_seen(dev):
