@@ -195,6 +195,11 @@ int mpc_last_solve_info2(mpc_handle *h, double *launch_pairs, int64_t *lbfgs_row
  * next iteration's Hessian-vector point, assuming the line-search trial is accepted) and how many of
  * them the next iteration consumed */
 int mpc_last_speculation(mpc_handle *h, int64_t *issued, int64_t *used);
+/* lookahead of the persistent kernel (Pacejka model, N <= 16, no constraints; environment MPC_NO_LOOKAHEAD at
+ * mpc_create turns it off; results do not depend on it): evaluations of points the state machine was GOING to ask
+ * for (next line-search trial points, deeper descent-lemma levels) executed in idle lanes beside a requested
+ * evaluation, and requests later served from them without an evaluation trip */
+int mpc_last_lookahead(mpc_handle *h, int64_t *evals, int64_t *hits);
 /* profile mode: summed HIP-event durations (ms) of the last solve's kernels,
  * out4 = [step_kernel, rollout_kernel (K1a), stage_kernel (K1b), adjoint_kernel (K1c)] */
 int mpc_last_kernel_ms(mpc_handle *h, double *out4);
@@ -207,7 +212,8 @@ int mpc_last_kernel_profile(mpc_handle *h, double *ms5, int64_t *launches5, int6
 int mpc_last_solo_ms(mpc_handle *h, double *sum_ms, double *longest_ms);
 /* A sub-batch group whose round holds at most `max_requests` evaluation requests leaves the rounds
  * and finishes in the persistent wave-per-agent kernel, and a batch of at most `max_requests` agents runs in
- * it from the start (0 = rounds only).  Defaults (measured): switch at 1024 requests; whole
+ * it from the start (0 = rounds only).  Defaults (measured): switch at 1024 requests (kinematic
+ * model) / 128 (Pacejka model, whose persistent-kernel waves take a whole SIMD each); whole
  * batches up to 4096 agents (kinematic, N <= 32) / 1024 (otherwise); environment
  * MPC_SOLO_MAX (both) and MPC_SOLO_ALL (the batch bound alone).  Results do not depend on it. */
 int mpc_set_solo_max(mpc_handle *h, int max_requests);

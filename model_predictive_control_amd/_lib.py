@@ -48,6 +48,7 @@ EXPORTS = [
     "mpc_eval_cost_grad_wave", "mpc_centerline_blocks", "mpc_set_nearest_blocks", "mpc_set_memo",
     "mpc_set_round_limit", "mpc_stream_concurrency", "mpc_last_solo_ms",
     "mpc_set_poll_timeout", "mpc_debug_spin", "mpc_debug_records", "mpc_debug_record_names", "mpc_source_hash",
+    "mpc_last_lookahead",
 ]
 NREC = 64
 
@@ -138,6 +139,7 @@ def load():
                                       C.POINTER(C.c_double)]
     L.mpc_last_solve_info2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.mpc_last_speculation.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.mpc_last_lookahead.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpc_math_probe.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     L.mpc_lane_payoff.argtypes = [vp, ci, ci, C.POINTER(C.c_double), vp, vp, vp, vp, vp]
     L.mpc_set_profile.argtypes = [vp, ci]

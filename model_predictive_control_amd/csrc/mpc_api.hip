@@ -71,13 +71,14 @@ struct mpc_handle {
                                 // (MPC_SOLO_ALL; measured: kinematic 4 096 agents 62.8 -> 53.3 ms, 8 192 worse; Pacejka 1 024)
     int solo_max = 1024;        // a group with at most this many requests per round finishes in the persistent
                                 // wave-per-agent kernel (MPC_SOLO_MAX / mpc_set_solo_max; 0 = rounds only).
-                                // Default 1024 (measured for both models and for N = 40: profiles/r02c_*)
+                                // Default 1024 (kinematic model, measured in round 2, also for N = 40: profiles/r02c_*),
+                                // 128 on the Pacejka model (round 4: mpc_create)
     int Bp_alloc = 0;      // workspace capacity (agents)
     char *arena = nullptr; // one device allocation carved into the Workspace arrays
     size_t arena_bytes = 0;
     Workspace ws{};
-    int *host_counts = nullptr; // pinned, 512 B: [2 poll windows][MPC_MAX_GROUPS][2] ints, then (byte 128) the eight totals of a
-                                // solve and (byte 192) the persistent kernel's counters -- copies into pageable memory would
+    int *host_counts = nullptr; // pinned, 512 B: [2 poll windows][MPC_MAX_GROUPS][2] ints, then (byte 128) the sixteen totals of a
+                                // solve (16 x 8 B) and (byte 256) the persistent kernel's counters -- copies into pageable memory would
                                 // block the host until the stream has drained, whatever the wall-clock bound says
     hipEvent_t pollev[2][MPC_MAX_GROUPS] = {{nullptr}};
     hipEvent_t soloev[MPC_MAX_GROUPS][2] = {{nullptr}}; // profile mode: around a group's persistent-kernel launch
@@ -90,6 +91,7 @@ struct mpc_handle {
     int64_t solo_agents = 0;    // agents finished by the persistent kernel in the last solve
     double solo_longest_ms = 0.0; // profile mode: the longest of the groups' persistent-kernel launches
     int64_t spec_issued = 0, spec_used = 0; // speculative channel-2 gradients of the last solve
+    int64_t la_evals = 0, la_hits = 0;      // persistent kernel's lookahead: candidate evaluations executed, requests served from them
     int64_t lbfgs_rows = 0; // history pairs read by K3 (each is read twice: 4*n*8 bytes per pair)
     std::vector<hipEvent_t> ev_pool;
     // sub-batch pipelining: the batch is split into groups that run their rounds on separate
@@ -207,6 +209,7 @@ static int make_devcfg(const mpc_config &c, DevCfg &d)
     d.max_total_evals = c.max_total_evals;
     d.no_spec = getenv("MPC_NO_SPEC") != nullptr;
     d.no_memo = getenv("MPC_NO_MEMO") != nullptr;
+    d.no_la = getenv("MPC_NO_LOOKAHEAD") != nullptr;
     d.all_rows = getenv("MPC_ALL_ROWS") != nullptr;
     // (MPC_NO_CHAIN: never; which launches carry them is decided per launch: chain_min)
     // (kinematic model only by default: measured on the Pacejka model, whose rounds wait for the rollout, 668 -> 699 ms per
@@ -310,7 +313,13 @@ extern "C" int mpc_create(const mpc_config *cfg, int device, mpc_handle **out)
     if (getenv("MPC_APB")) h->apb_env = atoi(getenv("MPC_APB"));
     h->fused_eval = getenv("MPC_UNFUSED_EVAL") == nullptr;
     if (getenv("MPC_FUSED_MAX")) h->fused_max = atoi(getenv("MPC_FUSED_MAX"));
-    h->solo_max = 1024;
+    // Pacejka model: 128.  Its persistent-kernel waves take a whole SIMD each (512 registers); the 2 237 agents that four
+    // groups hand over at 1 024 requests each are more than the chip's 1 024 SIMDs hold, the later groups' waves queue and
+    // the ones in flight starve the other groups' rounds, while a thin Pacejka round is no slower per evaluation than a
+    // lone wave's trip (round 4, same box, alternating, 65 536 agents, bit-identical: 1 024 -> 462 ms, 512 -> 447,
+    // 384 -> 426, 32 .. 256 -> 412 - 429).  Kinematic model: 1 024 as measured in round 2 (its trips are 4x shorter than
+    // a thin round, two waves per SIMD).
+    h->solo_max = cfg->model == MPC_MODEL_PACEJKA ? 128 : 1024;
     h->solo_all = (cfg->model == MPC_MODEL_KINEMATIC && cfg->N <= 32) ? 4096 : 1024;
     if (getenv("MPC_SOLO_MAX")) h->solo_max = h->solo_all = atoi(getenv("MPC_SOLO_MAX"));
     if (getenv("MPC_SOLO_ALL")) h->solo_all = atoi(getenv("MPC_SOLO_ALL"));
@@ -378,7 +387,7 @@ static int reserve(mpc_handle *h, int B)
     const size_t nd = 8 * n + 2 * M * n + 7 * m + REC;          // agent-major doubles per agent
     const size_t nscr = (N + 1) * nx + 2 * N + N + N * JS;       // K1 scratch doubles per slot
     const size_t ni = 4;                                         // list ints per agent
-    const size_t bytes = (nd * 8 + ni * 4) * (size_t)Bp + nscr * 8 * St + 4 * St + 8 * 4 * MPC_MAX_GROUPS + 256 +
+    const size_t bytes = (nd * 8 + ni * 4) * (size_t)Bp + nscr * 8 * St + 4 * St + 8 * 4 * MPC_MAX_GROUPS + 256 + 64 +
                          4 * (St / 64 + 16) + 256;
     char *base = nullptr;
     hipError_t e = hipMalloc((void **)&base, bytes);
@@ -401,7 +410,7 @@ static int reserve(mpc_handle *h, int B)
     w.agent_of = ip; ip += St;
     w.counts = ip; // 8 ints per group
     w.totals = (unsigned long long *)(ip + 8 * MPC_MAX_GROUPS);
-    w.solo_ctr = (int *)(w.totals + 8); // [group][claim counter, list length]
+    w.solo_ctr = (int *)(w.totals + 16); // [group][claim counter, list length]
     h->arrive_buf = w.solo_ctr + 2 * MPC_MAX_GROUPS + 32; // [St / 64 + 16]: stage blocks done per slot block
     w.arrive = nullptr;
     w.Bp = Bp; w.B = B; w.St = (int)St; w.Ls = Bp;
@@ -812,9 +821,17 @@ static void launch_solo_t(mpc_handle *h, const Workspace &v, hipStream_t s, int 
     int *list = listed ? v.lists : nullptr;   // the round lists are free once the group leaves the rounds
     if (listed)
         hipLaunchKernelGGL(solo_list_kernel, dim3((unsigned)((v.B + 255) / 256)), dim3(256), 0, s, v, list, ctr);
-    const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.nfe, c.N, c.n, c.M, MC < 0);
+    const bool la = NE == 1 && solo_lookahead(MODEL, c.nfe, c.N, c.m, c.no_la);
+    const size_t lds = sizeof(double) * SOLO_WAVES * solo_lds_doubles<MODEL>(c.nfe, c.N, c.n, c.M, MC < 0, la);
     int nblk = (bound + SOLO_WAVES - 1) / SOLO_WAVES;
     nblk = std::max(1, std::min(nblk, 4 * SoloOcc<MODEL, MC>::WPS * h->num_cus)); // what is resident (registers); the rest queues
+    if constexpr (MODEL == PAC && NE == 1) {
+        if (la) {
+            hipLaunchKernelGGL((solo_kernel<MODEL, NE, MC, true>), dim3((unsigned)nblk), dim3(64 * SOLO_WAVES), lds, s, c, v, list,
+                               ctr, max_trips);
+            return;
+        }
+    }
     hipLaunchKernelGGL((solo_kernel<MODEL, NE, MC>), dim3((unsigned)nblk), dim3(64 * SOLO_WAVES), lds, s, c, v, list,
                        ctr, max_trips);
 }
@@ -839,7 +856,8 @@ static bool solo_fits(const mpc_handle *h)
 {
     const DevCfg &c = h->dc;
     const bool hist = c.n <= 64 && !h->step_regs && c.M * c.n <= 800;
-    const size_t per = c.model == PAC ? solo_lds_doubles<PAC>(c.nfe, c.N, c.n, c.M, hist)
+    const bool la = c.n <= 64 && solo_lookahead(c.model, c.nfe, c.N, c.m, c.no_la);
+    const size_t per = c.model == PAC ? solo_lds_doubles<PAC>(c.nfe, c.N, c.n, c.M, hist, la)
                                       : solo_lds_doubles<KIN>(c.nfe, c.N, c.n, c.M, hist);
     return c.N <= 64 && per * SOLO_WAVES * sizeof(double) <= 64 * 1024;
 }
@@ -918,7 +936,7 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     const DevCfg &c = h->dc;
     Workspace &w = h->ws;
     const int B = w.B;
-    HIPCHK(hipMemsetAsync(w.counts, 0, 8 * MPC_MAX_GROUPS * sizeof(int) + 8 * sizeof(unsigned long long) +
+    HIPCHK(hipMemsetAsync(w.counts, 0, 8 * MPC_MAX_GROUPS * sizeof(int) + 16 * sizeof(unsigned long long) +
                                            2 * MPC_MAX_GROUPS * sizeof(int), s));
     hipLaunchKernelGGL(init_kernel, dim3((unsigned)(((size_t)B * REC + 255) / 256)), dim3(256), 0, s, c, w);
     if (w.arrive) HIPCHK(hipMemsetAsync(h->arrive_buf, 0, sizeof(int) * (size_t)(w.St / 64 + 16), s)); // (a failed launch may have left counts)
@@ -1149,14 +1167,15 @@ static int run_solver_rounds(mpc_handle *h, hipStream_t s)
     for (int g = 0; g < ng; g++) h->rounds = std::max<int64_t>(h->rounds, rounds_done[g]);
     {
         unsigned long long *tot = (unsigned long long *)((char *)h->host_counts + 128);   // pinned (see host_counts)
-        int *sctr = (int *)((char *)h->host_counts + 192);
-        static_assert(8 * sizeof(unsigned long long) == 64 && 2 * MPC_MAX_GROUPS * sizeof(int) == 64, "pinned staging layout");
+        int *sctr = (int *)((char *)h->host_counts + 256);
+        static_assert(16 * sizeof(unsigned long long) == 128 && 2 * MPC_MAX_GROUPS * sizeof(int) == 64, "pinned staging layout");
         hipLaunchKernelGGL(totals_kernel, grid_for(B, 256), dim3(256), 0, s, w);
-        HIPCHK(hipMemcpyAsync(tot, w.totals, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tot, w.totals, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(sctr, w.solo_ctr, 2 * MPC_MAX_GROUPS * sizeof(int), hipMemcpyDeviceToHost, s));
         { const int rs = bounded_sync(h, s, "mpc_solve_batch"); if (rs) return rs; }
         h->evals_grad = (int64_t)tot[0]; h->evals_cost = (int64_t)tot[1]; h->lbfgs_rows = (int64_t)tot[2];
         h->spec_issued = (int64_t)tot[4]; h->spec_used = (int64_t)tot[5];
+        h->la_evals = (int64_t)tot[7]; h->la_hits = (int64_t)tot[8];
         if (all_solo) h->solo_agents = B;
         else for (int g = 0; g < ng; g++) h->solo_agents += sctr[2 * g + 1];
         // every agent must have reached PH_DONE: the round path says so through its request counters, the
@@ -1312,6 +1331,15 @@ extern "C" int mpc_last_speculation(mpc_handle *h, int64_t *issued, int64_t *use
     return MPC_OK;
 }
 
+extern "C" int mpc_last_lookahead(mpc_handle *h, int64_t *evals, int64_t *hits)
+{
+    if (!h) return fail(MPC_E_ARG, "mpc_last_lookahead: null handle");
+    { const int rb = refuse_if_busy(h, "mpc_last_lookahead"); if (rb) return rb; }
+    if (evals) *evals = h->la_evals;
+    if (hits) *hits = h->la_hits;
+    return MPC_OK;
+}
+
 extern "C" int mpc_last_solve_info2(mpc_handle *h, double *launch_pairs, int64_t *lbfgs_rows)
 {
     if (!h) return fail(MPC_E_ARG, "mpc_last_solve_info2: null handle");
@@ -1449,8 +1477,8 @@ static const char *const k_record_names =
     "psi,L,gamma,phi,psixh,pp,gp,tau,psin,Ln,gamman,psixhn,gpn,ppn,sigpp,eps,hn2,hfd,gamma_top,Delta,rho,eps_old,ne1,ps_eps,"
     "out_eps,out_delta,psi_out,psie,phase,k,lidx,lfull,noprog,nJ,outer,first,initred,penred,inner_tot,inner_fail,status,"
     "nevals,maxit,overwrite,fallback,ps_status,ps_iters,out_of_iter,ngrad,lbrows,spec,spec_gamma,nspec,nspec_used,ncost,"
-    "run_mineps,run_ev0,memo_status,memo_iters,memo_evals,memo_mineps,memo_eps";
-static_assert(R_USED == 62 && REC == MPC_NREC, "k_record_names / MPC_NREC must follow the record enum");
+    "run_mineps,run_ev0,memo_status,memo_iters,memo_evals,memo_mineps,memo_eps,la_evals,la_hits";
+static_assert(R_USED == 64 && REC == MPC_NREC, "k_record_names / MPC_NREC must follow the record enum");
 extern "C" const char *mpc_debug_record_names(void) { return k_record_names; }
 extern "C" int mpc_debug_records(mpc_handle *h, int B, double *host_out)
 {

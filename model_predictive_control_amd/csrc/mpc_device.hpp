@@ -31,6 +31,7 @@ struct DevCfg {
                          // groups only; MPC_NO_CHAIN: never -- same results)
     int all_rows;        // MPC_ALL_ROWS: the step kernel fetches all six rows of an agent whatever its phase (same results)
     int no_memo;         // MPC_NO_MEMO / mpc_set_memo(h, 0): failed retries are recomputed, not replayed (same results)
+    int no_la;           // MPC_NO_LOOKAHEAD: the persistent kernel evaluates only what the state machine asks for (same results)
     double h;      // RK4 step Ts / nfe
     double v_ref;
     double w[6];

@@ -550,20 +550,20 @@ __device__ __forceinline__ void stage_sens_record(const DevCfg &c, const double 
 
 // K1c for one request: psi = sum of stage costs (stage order, as main.py:36-40) and the adjoint
 // recursion over the stage records; `get(k, f)` reads field f of stage k.
+// (the same with the destinations given: psi -> *psi_out (may be null), gradient -> grow[2N]; the persistent kernel's
+// lookahead sends candidate evaluations to its cache)
 template <int MODEL, class Get>
-__device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g, Get get)
+__device__ __forceinline__ void adjoint_rec_to(const DevCfg &c, bool is_g, Get get, double *psi_out, double *grow)
 {
     constexpr int NX = ModelDim<MODEL>::NX, NZ = NX - 2, JS = JacRec<MODEL>::SIZE;
-    const int N = c.N, n = c.n;
+    const int N = c.N;
     double psi = 0.0;
     for (int k = 0; k < N; k++) psi += get(k, JS);
-    if (w.psi_direct) w.psi_direct[a] = psi;
-    else if (!ch2) w.rec[(size_t)a * REC + R_PSIE] = psi;
+    if (psi_out) *psi_out = psi;
     if (!is_g) return;
     double lam[NX];
 #pragma unroll
     for (int i = 0; i < NX; i++) lam[i] = 0.0;
-    double *grow = (ch2 ? w.ge2 : w.ge) + (size_t)a * n;
     for (int k = N - 1; k >= 0; k--) {
 #pragma unroll
         for (int i = 0; i < NX; i++) lam[i] += get(k, i);
@@ -589,6 +589,12 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
         grow[2 * k] = gu[0];
         grow[2 * k + 1] = gu[1];
     }
+}
+template <int MODEL, class Get>
+__device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w, int a, bool ch2, bool is_g, Get get)
+{
+    double *psi_out = w.psi_direct ? w.psi_direct + a : !ch2 ? w.rec + (size_t)a * REC + R_PSIE : nullptr;
+    adjoint_rec_to<MODEL>(c, is_g, get, psi_out, (ch2 ? w.ge2 : w.ge) + (size_t)a * c.n);
 }
 
 // K1b.  With `w.arrive` set it also does K1c for a block of 64 slots, in the stage-block that finishes

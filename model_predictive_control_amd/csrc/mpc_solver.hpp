@@ -24,7 +24,10 @@ enum {
     R_PS_ITERS, R_OUT_OF_ITER, R_NGRAD, R_LBROWS, R_SPEC, R_SPEC_GAMMA, R_NSPEC, R_NSPEC_USED, R_NCOST,
     // the inner solve in progress (smallest stop measure seen, evaluation count at its start) and the memo of
     // the last one that failed and was backtracked over without constraints (see PH_OUTER_BEGIN)
-    R_RUN_MINEPS, R_RUN_EV0, R_MEMO_STATUS, R_MEMO_ITERS, R_MEMO_EVALS, R_MEMO_MINEPS, R_MEMO_EPS, R_USED
+    R_RUN_MINEPS, R_RUN_EV0, R_MEMO_STATUS, R_MEMO_ITERS, R_MEMO_EVALS, R_MEMO_MINEPS, R_MEMO_EPS,
+    // persistent kernel's lookahead (mpc_solo.hpp): candidate evaluations executed beside requested ones, requests served
+    // from them without a trip (plain double counters)
+    R_LA_EVALS, R_LA_HITS, R_USED
 };
 static_assert(R_USED <= REC, "record too small");
 // The integers of the record (phase, counters, flags: all >= 0) are stored as the double 2^52 + k, whose low dword IS
@@ -75,7 +78,8 @@ struct Workspace {
     double *rec;                                   // [B][REC]
     int *lists;                                    // [2 buffers][2 kinds][Bp] agent ids
     int *counts;                                   // [2 buffers][4]
-    unsigned long long *totals;                    // [8] gradient evals, cost evals, history pairs read, harness, spec issued/used
+    unsigned long long *totals;                    // [16] gradient evals, cost evals, history pairs read, harness, spec issued/used,
+                                                   //      unfinished agents, lookahead evaluations / hits
     int *solo_ctr;                                 // [groups][2] persistent kernel: claim counter, list length
     // K1 scratch, slot-indexed SoA with stride Bp + 64 (see mpc_eval.hpp)
     double *trajx;                                 // [(N+1)*nx][St] x_0 .. x_N
@@ -494,6 +498,49 @@ __device__ __forceinline__ bool lbfgs_two_loop(const DevCfg &c, const double *__
     return true;
 }
 
+// The line-search trial point for step tau (PH_LS_TRIAL) and the point of the speculative Hessian-vector gradient
+// (speculate / PH_AFTER_DL): one function each for the state machine and for the persistent kernel's lookahead
+// (mpc_solo.hpp), which forms the SAME points ahead of the state machine and must get the same bits.
+template <int NE>
+__device__ __forceinline__ Row<NE> trial_point(const DevCfg &c, int par, const Row<NE> &x, const Row<NE> &g,
+                                               const Row<NE> &qv, double gamma, double tau, bool fallback)
+{
+#pragma clang fp contract(off)
+    Row<NE> r;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const double p = prox_p(c, par, x.v[e], g.v[e], gamma);
+        if (fallback) r.v[e] = x.v[e] + p;
+        else if (tau == 1.0) r.v[e] = x.v[e] + qv.v[e];
+        else r.v[e] = x.v[e] + (1.0 - tau) * p + tau * qv.v[e];
+    }
+    return r;
+}
+// returns |J| (the point exists when 0 < |J| < n); all 64 lanes must call it
+template <int NE>
+__device__ __forceinline__ int spec_point(const DevCfg &c, int par, int n, int lane, const Row<NE> &xn, const Row<NE> &ge,
+                                          double gm, Row<NE> &out)
+{
+#pragma clang fp contract(off)
+    Row<NE> qv;
+    double cntJ = 0.0, xx = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const bool valid = lane + 64 * e < n;
+        const bool in = in_J(c, par, xn.v[e], ge.v[e], gm);
+        qv.v[e] = in ? 0.0 : prox_p(c, par, xn.v[e], ge.v[e], gm);
+        if (valid) { cntJ += in ? 1.0 : 0.0; xx += xn.v[e] * xn.v[e]; }
+    }
+    wave_sum2_n(cntJ, xx, n);
+    const int nj = (int)cntJ;
+    if (nj > 0 && nj < n) {
+        const double h = fd_step(xx);
+#pragma unroll
+        for (int e = 0; e < NE; e++) out.v[e] = xn.v[e] + h * qv.v[e];
+    }
+    return nj;
+}
+
 // K5 helper: alpaqa detail::update_penalty_weights (per-constraint factors), lanes stride over m
 __device__ __forceinline__ void update_penalty(const DevCfg &c, const Workspace &w, size_t am, int lane,
                                                double Delta, int first, double ne1)
@@ -644,23 +691,10 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
     // inputs, so the point -- and the gradient -- are bit-identical when the assumption holds.
     auto speculate = [&](double gm) {
         if (c.no_spec || !allow_spec) { spec = 0; return; }
-        Row<NE> qv;
-        double cntJ = 0.0, xx = 0.0;
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-            const bool valid = lane + 64 * e < n;
-            const bool in = in_J(c, par, XN.v[e], GE.v[e], gm);
-            qv.v[e] = in ? 0.0 : prox_p(c, par, XN.v[e], GE.v[e], gm);
-            if (valid) { cntJ += in ? 1.0 : 0.0; xx += XN.v[e] * XN.v[e]; }
-        }
-        wave_sum2_n(cntJ, xx, n);
-        const int nj = (int)cntJ;
+        Row<NE> xh;
+        const int nj = spec_point<NE>(c, par, n, lane, XN, GE, gm, xh);
         spec = 0;
         if (nj > 0 && nj < n) {
-            const double h = fd_step(xx);
-            Row<NE> xh;
-#pragma unroll
-            for (int e = 0; e < NE; e++) xh.v[e] = XN.v[e] + h * qv.v[e];
             strow<NE>(w.xe2 + an, n, lane, xh);
             spec = 1; spec_gamma = gm;
             req |= REQ_SPEC; n_spec = 1;
@@ -923,16 +957,7 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
         case PH_LS_TRIAL: {
             Ln = Lk; gamman = gamma;
             fallback = tau / 2.0 < c.tau_min; // safe prox step: x+ = xhat, psi+ = psi(xhat)
-            Row<NE> x = X;
-            const Row<NE> g = G;
-            const Row<NE> qv = Q;
-#pragma unroll
-            for (int e = 0; e < NE; e++) {
-                const double p = prox_p(c, par, x.v[e], g.v[e], gamma);
-                if (fallback) x.v[e] = x.v[e] + p;
-                else if (tau == 1.0) x.v[e] = x.v[e] + qv.v[e];
-                else x.v[e] = x.v[e] + (1.0 - tau) * p + tau * qv.v[e];
-            }
+            const Row<NE> x = trial_point<NE>(c, par, X, G, Q, gamma, tau, fallback != 0);
             XN = x;
             strow<NE>(w.xn + an, n, lane, x); strow<NE>(w.xe + an, n, lane, x);
             // (round path: the entry is marked as "gradient at a trial point" whether or not the NEXT launch will
@@ -1398,14 +1423,16 @@ __global__ void init_kernel(const DevCfg c, const Workspace w)
 __global__ void __launch_bounds__(256) totals_kernel(const Workspace w)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    double ng = 0.0, nc = 0.0, lr = 0.0, ns = 0.0, nu = 0.0;
+    double ng = 0.0, nc = 0.0, lr = 0.0, ns = 0.0, nu = 0.0, le = 0.0, lh = 0.0;
     bool unfinished = false;
     if (a < w.B) {
         const double *r = w.rec + (size_t)a * REC;
         ng = r[R_NGRAD]; nc = r[R_NCOST]; lr = r[R_LBROWS]; ns = r[R_NSPEC]; nu = r[R_NSPEC_USED];
+        le = r[R_LA_EVALS]; lh = r[R_LA_HITS];
         unfinished = rec_int_of(r[R_PHASE]) != PH_DONE;
     }
     ng = wave_sum(ng); nc = wave_sum(nc); lr = wave_sum(lr); ns = wave_sum(ns); nu = wave_sum(nu);
+    le = wave_sum(le); lh = wave_sum(lh);
     const unsigned long long unf = __ballot(unfinished);
     if ((threadIdx.x & 63) == 0) {
         // agents a solve left unfinished (the persistent kernel's trip guard ran out): the host reports MPC_E_LIMIT
@@ -1415,6 +1442,8 @@ __global__ void __launch_bounds__(256) totals_kernel(const Workspace w)
         atomicAdd(&w.totals[2], (unsigned long long)lr);
         atomicAdd(&w.totals[4], (unsigned long long)ns);   // speculative gradients issued / consumed
         atomicAdd(&w.totals[5], (unsigned long long)nu);
+        if (le != 0.0) atomicAdd(&w.totals[7], (unsigned long long)le);   // lookahead: candidate evaluations executed
+        if (lh != 0.0) atomicAdd(&w.totals[8], (unsigned long long)lh);   // ... requests served from them
     }
 }
 

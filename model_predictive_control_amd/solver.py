@@ -363,6 +363,8 @@ class BatchedMPC:
         _lib.check(self.lib.mpc_last_solve_info2(self._h, C.byref(lm), C.byref(lr)))
         si, su = C.c_int64(), C.c_int64()
         _lib.check(self.lib.mpc_last_speculation(self._h, C.byref(si), C.byref(su)))
+        le, lh = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.mpc_last_lookahead(self._h, C.byref(le), C.byref(lh)))
         km = (C.c_double * 5)()
         kl = (C.c_int64 * 5)()
         sa = C.c_int64()
@@ -374,5 +376,5 @@ class BatchedMPC:
                 "launches": {k: int(kl[i]) for i, k in enumerate(names)}, "solo_agents": int(sa.value),
                 "rounds": r.value, "evals_grad": g.value, "evals_cost": c.value,
                 "eval_ms": e.value, "step_ms": s.value, "launch_pairs": int(lm.value), "lbfgs_rows": lr.value,
-                "spec_issued": si.value, "spec_used": su.value, "groups": self.stream_concurrency()[1],
+                "spec_issued": si.value, "spec_used": su.value, "lookahead_evals": le.value, "lookahead_hits": lh.value, "groups": self.stream_concurrency()[1],
                 "solo_longest_ms": slong.value}

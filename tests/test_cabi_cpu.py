@@ -138,6 +138,6 @@ def test_debug_record_names_follow_the_record_layout(L):
     """mpc_debug_record_names(): one name per slot in use of the per-agent solver record (static_assert in
     mpc_api.hip ties the count to the enum), no duplicates, within MPC_NREC."""
     names = L.mpc_debug_record_names().decode().split(",")
-    assert len(names) == len(set(names)) == 62 and len(names) <= _lib.NREC
+    assert len(names) == len(set(names)) == 64 and len(names) <= _lib.NREC
     for must in ("L", "gamma", "tau", "nJ", "lidx", "lfull", "nevals", "k", "outer", "fallback", "phase"):
         assert must in names

@@ -443,6 +443,36 @@ def test_statistics_getters_are_refused_while_a_solve_is_in_flight(dev):
     assert eng.last_solve_info()["rounds"] > 0 and (st[:, 0] == 1).all()
 
 
+@pytest.mark.parametrize("N,B", [(12, 700), (16, 200), (5, 130)])
+def test_lookahead_changes_nothing_but_the_trips(dev, monkeypatch, N, B):
+    """The persistent kernel's lookahead (Pacejka model, N <= 16, no constraints: candidate evaluations in the idle
+    lanes of a trip, requests served from them later) against the same kernel without it (MPC_NO_LOOKAHEAD) and
+    against the round path: the same controls and the same eight statistics per agent, bit for bit -- a cached
+    evaluation is the evaluation --, with requests actually served from the cache."""
+    rng = np.random.default_rng(N)
+    X0 = synthetic_states(1, B, seed=20 + N)
+    X0[: B // 8, 3] = rng.uniform(0.05, 0.3, B // 8)          # slow cars: wild line searches, descent-lemma loops
+    cl = T(straight_centerline(), dev)
+    X0d, U0d = T(X0, dev), T(np.tile([1.0, 0.0], (B, N)), dev)
+    kw = dict(max_total_inner=600)
+    eng = mp.BatchedMPC(mp.default_config(1, N, **kw), dev)
+    eng.set_solo_max(100000)
+    U1, _, s1 = eng.solve(X0d, cl, U0d)
+    i1 = eng.last_solve_info()
+    assert i1["solo_agents"] == B and i1["lookahead_hits"] > 0 and i1["lookahead_evals"] >= i1["lookahead_hits"]
+    monkeypatch.setenv("MPC_NO_LOOKAHEAD", "1")
+    plain = mp.BatchedMPC(mp.default_config(1, N, **kw), dev)
+    monkeypatch.delenv("MPC_NO_LOOKAHEAD")
+    plain.set_solo_max(100000)
+    U2, _, s2 = plain.solve(X0d, cl, U0d)
+    i2 = plain.last_solve_info()
+    assert i2["lookahead_hits"] == 0 and i2["lookahead_evals"] == 0
+    assert torch.equal(U1, U2) and torch.equal(s1, s2)
+    eng.set_solo_max(0)
+    U3, _, s3 = eng.solve(X0d, cl, U0d)
+    assert eng.last_solve_info()["rounds"] > 0 and torch.equal(U1, U3) and torch.equal(s1, s3)
+
+
 def test_round_limit_is_reported_on_both_paths(dev):
     """A solve that does not finish inside the round limit returns MPC_E_LIMIT -- from the round loop (request
     counters) and from the persistent kernel (whose trip guard leaves an agent where it stands: the host counts
