@@ -508,6 +508,9 @@ def main():
                 "solo_kernel_ms_longest": infk["solo_longest_ms"], "solo_kernel_share": infk["solo_longest_ms"] / (sec * 1e3),
                 "solo_kernel_ms_sum_over_groups": infk["kernel_ms"]["solo"],
                 "kernel_ms_one_profiled_solve": infk["kernel_ms"],
+                "lookahead": {"candidate_evaluations": infs["lookahead_evals"], "requests_served_from_them": infs["lookahead_hits"],
+                              "note": "persistent kernel only: points the state machine was going to ask for, evaluated in the idle "
+                                      "lanes of a trip (not counted in E_g / E_f of the roofline: they cost no trip)"},
                 "roofline": {"bound": "hbm", "achieved": alg_p * B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg_p * B / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "algorithmic_bytes_per_solve": alg_p,

@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd $R
-for V in "MPC_SOLO_MAX=32" "MPC_SOLO_MAX=64" "MPC_SOLO_MAX=128" "MPC_SOLO_MAX=192" "MPC_SOLO_MAX=256" "MPC_SOLO_MAX=32" "MPC_SOLO_MAX=64" "MPC_SOLO_MAX=128" "MPC_SOLO_MAX=192" "MPC_SOLO_MAX=256" "MPC_SOLO_MAX=128 MPC_NO_LOOKAHEAD=1" "MPC_SOLO_MAX=256 MPC_NO_LOOKAHEAD=1"; do
-env $V MPC_SOLO_ALL=1024 timeout -k 10 300 python - <<'PY'
+for V in "MPC_PAC_QUAD_MAX=24576" "MPC_PAC_QUAD_MAX=12288" "MPC_PAC_QUAD_MAX=8192" "MPC_PAC_QUAD_MAX=16384" "MPC_PAC_QUAD_MAX=24576 MPC_GROUPS=3" "MPC_PAC_QUAD_MAX=24576 MPC_WIDE_MAX=4096 MPC_FUSED_MAX=0" "MPC_PAC_QUAD_MAX=24576" "MPC_PAC_QUAD_MAX=12288"; do
+env $V timeout -k 10 300 python - <<'PY'
 import os, sys, time, hashlib
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -16,7 +16,7 @@ U0 = torch.tensor([1.0, 0.0], dtype=torch.float64, device=dev).repeat(B, N)
 sec, U, st, inf = bench.timed_solves(eng, X, cl, U0, dev, steps=3)
 eng.set_profile(True); eng.solve(X, cl, U0); k = eng.last_solve_info()
 print("[%s] Pacejka 65536: %.1f ms %.0f solves/s rounds %d solo_agents %d longest solo %.1f ms hits %d sha %s"
-      % (os.environ.get("MPC_SOLO_MAX"), sec * 1e3, B / sec, inf["rounds"], inf["solo_agents"], k["solo_longest_ms"],
+      % (os.environ.get("MPC_PAC_QUAD_MAX","") + " " + os.environ.get("MPC_GROUPS",""), sec * 1e3, B / sec, inf["rounds"], inf["solo_agents"], k["solo_longest_ms"],
          inf["lookahead_hits"], hashlib.sha256(np.ascontiguousarray(U.cpu().numpy()).tobytes()).hexdigest()[:12]), flush=True)
 PY
 done
