@@ -771,6 +771,16 @@ static void launch_step_t(mpc_handle *h, const Workspace &w, hipStream_t s, int 
         const int fit = (int)((160 * 1024 / 4 - 512) / per_pair);
         P = std::max(1, std::min(P, fit));
     }
+    if (MC < 0 && NE == 2) {
+        // two elements per lane (n > 64; BASELINE config 3: N = 40, n = 80, M = 40), compiled for three waves per SIMD => three
+        // workgroups per CU; the LDS copy holds what fits a third of a CU's LDS -- 10 pairs of 2 x 640 B per wave at n = 80, where an
+        // application reads 11.7 pairs on average -- the rest of a long history comes from global memory.
+        // Round 4: this replaces the global-memory two-loop (MC = 0), which read every pair twice: 574 GB per solve of
+        // config 3 at full size.
+        const size_t per_pair = (size_t)STEP_WAVES * 2 * h->dc.n * sizeof(double);
+        const int fit = (int)((160 * 1024 / 3 - 1024) / per_pair);
+        P = std::max(1, std::min(P, fit));
+    }
     if (h->lds_pairs > 0) P = std::max(1, std::min(h->dc.M, h->lds_pairs));   // MPC_LDS_PAIRS: experiments, tests
     size_t lds = MC < 0 ? (size_t)STEP_WAVES * 2 * P * h->dc.n * sizeof(double) : 0;
     // thread-per-agent blocks for the agents that wait in PH_W_LS_G (chain_block): one per 64 gradient slots the
@@ -807,7 +817,8 @@ static void launch_step(mpc_handle *h, const Workspace &w, hipStream_t s, int *l
         if (!h->step_regs && c.M * c.n <= 800) launch_step_t<1, -1>(h, w, s, lists, counts, counts_next, slot_bound, par);
         else if (c.M <= 20) launch_step_t<1, 20>(h, w, s, lists, counts, counts_next, slot_bound, par);
         else launch_step_t<1, 0>(h, w, s, lists, counts, counts_next, slot_bound, par);
-    } else launch_step_t<2, 0>(h, w, s, lists, counts, counts_next, slot_bound, par);
+    } else if (!h->step_regs) launch_step_t<2, -1>(h, w, s, lists, counts, counts_next, slot_bound, par);
+    else launch_step_t<2, 0>(h, w, s, lists, counts, counts_next, slot_bound, par);   // MPC_STEP_REGS: the global-memory two-loop
 }
 
 // The persistent wave-per-agent kernel for the agents of view `v` that are still running (`listed`:

@@ -1015,7 +1015,13 @@ __device__ int advance_agent(const DevCfg &c, const Workspace &w, int a, int lan
                     // the prefetched LDS copy of the history gets the new pair too; the wait comes before
                     // this step's first global stores so that it does not have to drain them
                     hist_wait(); hist_landed = true;
-                    if (lane < n && lidx < P) { hist[(int)lidx * n + lane] = s.v[0]; hist[(P + (int)lidx) * n + lane] = yv.v[0]; }
+                    if (lidx < P) {
+#pragma unroll
+                        for (int e = 0; e < NE; e++) {
+                            const int j = lane + 64 * e;
+                            if (j < n) { hist[(int)lidx * n + j] = s.v[e]; hist[(P + (int)lidx) * n + j] = yv.v[e]; }
+                        }
+                    }
                 }
                 strow<NE>(w.S + ((size_t)a * c.M + lidx) * n, n, lane, s);
                 strow<NE>(w.Y + ((size_t)a * c.M + lidx) * n, n, lane, yv);
@@ -1283,7 +1289,7 @@ constexpr int STEP_WAVES = 4;
 // registers: held to 128 it runs four waves per SIMD, with the LDS copy of the history capped at P pairs so that
 // four workgroups share a CU; every other variant keeps its two or three)
 template <int NE, int MC, bool HASM>
-__global__ void __launch_bounds__(64 * STEP_WAVES, (NE == 1 && MC < 0 && !HASM) ? MPC_STEP_WAVES_LEAN : 2)
+__global__ void __launch_bounds__(64 * STEP_WAVES, (NE == 1 && MC < 0 && !HASM) ? MPC_STEP_WAVES_LEAN : (NE == 2 && MC < 0) ? 3 : 2)
 step_kernel(const DevCfg c, const Workspace w, int *__restrict__ lists_out,
             int *__restrict__ counts_out, int *__restrict__ counts_next, int apb, int nstep, int par, int P)
 {

@@ -971,6 +971,25 @@ def test_step_kernel_variants_are_bit_identical(dev, monkeypatch):
     U32, _, st32 = mp.BatchedMPC(mp.default_config(0, 32, max_total_inner=600), dev).solve(
         X0, cl, T(np.tile([1., 0.], (B, 32)), dev))
     assert (st32[:, 0] == 1).float().mean() >= 0.95 and torch.isfinite(U32).all()
+    # two elements per lane (N = 40, n = 80, M = 40; BASELINE config 3's kernel): since round 4 the history goes through the
+    # LDS copy capped at what fits (15 pairs), the ring slots beyond it from global memory -- against the global-memory
+    # two-loop of rounds 1 - 3 (MPC_STEP_REGS) and against a copy of three pairs only, unconstrained and with the lane band
+    B4 = 200
+    X4 = T(synthetic_states(0, B4, seed=9), dev)
+    U4 = T(np.tile([1., 0.], (B4, 40)), dev)
+    for kw in (dict(max_total_inner=400), dict(constr_mode=2, lane_halfwidth=0.05, Sigma0=10.0, max_total_inner=400, max_total_evals=2500)):
+        c4 = mp.default_config(0, 40, **kw)
+        Ud, ld, sd = mp.BatchedMPC(c4, dev).solve(X4, cl, U4)
+        monkeypatch.setenv("MPC_STEP_REGS", "1")
+        Ur, lr, sr = mp.BatchedMPC(c4, dev).solve(X4, cl, U4)
+        monkeypatch.delenv("MPC_STEP_REGS")
+        monkeypatch.setenv("MPC_LDS_PAIRS", "3")
+        U3, l3, s3 = mp.BatchedMPC(c4, dev).solve(X4, cl, U4)
+        monkeypatch.delenv("MPC_LDS_PAIRS")
+        assert torch.equal(Ud, Ur) and torch.equal(sd, sr) and torch.equal(Ud, U3) and torch.equal(sd, s3)
+        if ld is not None:
+            assert torch.equal(ld, lr) and torch.equal(ld, l3)
+        assert (sd[:, 2] > 40).float().mean() > 0.5              # long enough for histories beyond the copy
 
 
 @pytest.mark.parametrize("N", [20, 40])
