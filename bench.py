@@ -407,6 +407,15 @@ def main():
                 fp64["k1_only"] = {"achieved": k1, "frac": k1 / FP64_VALU_PEAK_TF, "ms_per_solve": k1_ms,
                                    "kernels": "K1a+K1b+K1c on the single-group pass (their own time, no overlap "
                                               "with the step kernel), the useful F"}
+        if pmc and pmc.get("sq_valu_wave_insts_per_solve_total"):
+            # the counter-based sibling of the modelled fraction: vector instructions the kernels ISSUED per
+            # solve (SQ_INSTS_VALU of the profiled run of this build) against the issue slots of the chip in a step, at the
+            # 4 cycles an fp64 FMA holds a SIMD-32 (other vector instructions hold it for 2: an upper bound of the share)
+            vi = float(pmc["sq_valu_wave_insts_per_solve_total"])
+            fp64["issue_based"] = {"valu_wave_instructions_per_solve": vi, "source": pmc_src,
+                                   "simd_issue_share_at_4_cycles": vi * 4.0 / (256 * 4 * 2.4e9 * step_s),
+                                   "note": "counted instructions of the profiled run (one solve on one stream), time of this run; "
+                                           "256 CUs x 4 SIMDs at 2.4 GHz"}
         dk = kernels.get(dominant + "_kernel") if dominant else None
         out = {
             "metric": "MPC solves/sec, bicycle model N=20 nx=4 nu=2, batch=65536; 1/2/4/8 GPU",

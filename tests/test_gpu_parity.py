@@ -449,6 +449,7 @@ def test_lookahead_changes_nothing_but_the_trips(dev, monkeypatch, N, B):
     lanes of a trip, requests served from them later) against the same kernel without it (MPC_NO_LOOKAHEAD) and
     against the round path: the same controls and the same eight statistics per agent, bit for bit -- a cached
     evaluation is the evaluation --, with requests actually served from the cache."""
+    monkeypatch.delenv("MPC_NO_LOOKAHEAD", raising=False)     # (the switch is the subject: set below for the plain engine)
     rng = np.random.default_rng(N)
     X0 = synthetic_states(1, B, seed=20 + N)
     X0[: B // 8, 3] = rng.uniform(0.05, 0.3, B // 8)          # slow cars: wild line searches, descent-lemma loops

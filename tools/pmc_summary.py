@@ -84,6 +84,15 @@ for k, cname, v in counter_rows("sq"):
     sq[k][cname] += v
     if cname == "SQ_WAVES":
         nd[k] += 1
+# the VALU instruction count of ONE solve (the SQ pass runs bench.py --steps 1 --warmup 0 on one stream) goes into the
+# counter summary too: bench.py's issue-based sibling of the modelled flop fraction
+try:
+    sj = json.load(open(os.path.join(PROF, tag + "_pmc_summary.json")))
+    sj["sq_valu_wave_insts_per_solve"] = {k: v.get("SQ_INSTS_VALU", 0.0) for k, v in sq.items() if v.get("SQ_INSTS_VALU", 0.0) > 1e6}
+    sj["sq_valu_wave_insts_per_solve_total"] = sum(sj["sq_valu_wave_insts_per_solve"].values())
+    json.dump(sj, open(os.path.join(PROF, tag + "_pmc_summary.json"), "w"), indent=1)
+except Exception as e:
+    print("no SQ totals in the summary:", e)
 with open(os.path.join(PROF, tag + "_sq_counters.txt"), "w") as fo:
     fo.write("rocprofv3 --kernel-trace --pmc SQ_* of bench.py --steps 1 --warmup 0, MPC_GROUPS=1 (no overlap), profile %s\n"
              "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves\n" % tag)
