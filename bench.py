@@ -384,10 +384,15 @@ def main():
                        "share_of_kernel_time": ms / tot_ms if tot_ms > 0 else None,
                        "model_bytes_per_solve": model.get(k, 0),
                        "model_GBps": model.get(k, 0) / (ms * 1e-3) / 1e9}
-                if pmc and (k + "_kernel") in pmc:
+                # the kernels the counters name for this slot of the round (K1a has three forms, K1b runs fused with K1c
+                # on the kinematic model)
+                names = {"step": ["step_kernel"], "rollout": ["rollout_kernel", "rollout_pair_kernel", "rollout_quad_kernel", "rollout_wide_kernel"],
+                         "stage": ["stage_kernel", "stage_adjoint_kernel"], "adjoint": ["adjoint_kernel"], "solo": ["solo_kernel"]}.get(k, [])
+                got = [pmc[nm].get("hbm_bytes_per_solve_corrected", 0.0) for nm in names if pmc and isinstance(pmc.get(nm), dict)]
+                if got:
                     # both byte figures per SOLVE (the counter passes run the default four groups, i.e. quarter-size
                     # launches; this pass one group: per launch they are not comparable, per solve they are)
-                    ent["pmc_hbm_bytes_per_solve"] = pmc[k + "_kernel"].get("hbm_bytes_per_solve_corrected")
+                    ent["pmc_hbm_bytes_per_solve"] = float(sum(got))
                     ent["pmc_source"] = pmc_src
                 kernels[k + "_kernel"] = ent
             dominant = max(kms, key=kms.get)
