@@ -597,6 +597,49 @@ __device__ __forceinline__ void adjoint_rec(const DevCfg &c, const Workspace &w,
     adjoint_rec_to<MODEL>(c, is_g, get, psi_out, (ch2 ? w.ge2 : w.ge) + (size_t)a * c.n);
 }
 
+// The same recursion for the kinematic model (NX = 4) by a QUAD of lanes per request: lane c keeps component c of the
+// adjoint, lanes 0 / 1 form the two input gradients of a stage, lanes 2 / 3 the two non-position adjoint components
+// (the position components only collect dL/dx); a stage is one add, four quad broadcasts and a chain of four fma per
+// lane instead of ~45 dependent-issue instructions on one lane.  Every sum is formed from the same operands in the
+// same order as adjoint_rec_to forms it: same bits (the fused kernel uses this form, the two-kernel path and the
+// persistent kernel the one-lane form: test_wide_rollout_is_bit_identical and the MPC_UNFUSED_EVAL suite compare them).
+// Why: the fused K1b+K1c workgroup holds its 44 KB of stage records in LDS for as long as this recursion runs on ONE
+// wave of its four -- half of the workgroup's life (profiles/r03_experiments.txt 29) -- and three such workgroups are all
+// a CU holds.  All four lanes of a quad must call it together (same request).
+template <class Get>
+__device__ __forceinline__ void adjoint_rec_quad_kin(const DevCfg &c, bool is_g, int comp, Get get, double *psi_out, double *grow)
+{
+    constexpr int NX = 4, NZ = 2, JS = JacRec<KIN>::SIZE;
+    const int N = c.N;
+    if (comp == 0) {
+        double psi = 0.0;
+        for (int k = 0; k < N; k++) psi += get(k, JS);
+        if (psi_out) *psi_out = psi;
+    }
+    if (!is_g) return;                                   // (uniform within the quad)
+    const int dd = (comp + 2) & 3;                       // the row of the sensitivity block this lane multiplies by
+    double lam = 0.0;
+    for (int k = N - 1; k >= 0; k--) {
+        lam += get(k, comp);
+        const double l0 = quad_bcast<0x00>(lam), l1 = quad_bcast<0x55>(lam), l2 = quad_bcast<0xAA>(lam), l3 = quad_bcast<0xFF>(lam);
+        double acc = comp < 2 ? get(k, NX + comp) : 0.0;
+        // row dd of the block; its constant entries are not stored (sens_is_const): heading row (dd = 0) [., ., 1, 0],
+        // steering row (dd = 3) [., ., ., 0]
+        const double t0 = get(k, NX + 2 + dd * NX + 0), t1 = get(k, NX + 2 + dd * NX + 1);
+        const double t2 = dd == 0 ? 1.0 : get(k, NX + 2 + dd * NX + 2);
+        const double t3 = (dd == 0 || dd == 3) ? 0.0 : get(k, NX + 2 + dd * NX + 3);
+        acc = fma(t0, l0, acc);
+        acc = fma(t1, l1, acc);
+        acc = fma(t2, l2, acc);
+        acc = fma(t3, l3, acc);
+        if (comp < 2) grow[2 * k + comp] = acc;          // the input gradients of the stage
+        else lam = acc;                                  // lam[2 + jj] = lz[jj]
+    }
+    static_assert(sens_is_const<KIN>(0, 2) && sens_is_const<KIN>(0, 3) && sens_is_const<KIN>(3, 3) && !sens_is_const<KIN>(3, 2) &&
+                  !sens_is_const<KIN>(1, 3) && !sens_is_const<KIN>(2, 3) && !sens_is_const<KIN>(0, 1), "constant entries of the kinematic block");
+    (void)NZ;
+}
+
 // K1b.  With `w.arrive` set it also does K1c for a block of 64 slots, in the stage-block that finishes
 // last (arrival counter per slot block): the records are stored write-through (sc1: relaxed
 // agent-scope atomic stores, so no release fence), the wave drains its stores, one lane adds to the
@@ -763,6 +806,20 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
         }
     }
     __syncthreads();
+    if constexpr (MODEL == KIN) {
+        // the adjoint recursion by a quad of lanes per request (adjoint_rec_quad_kin): 4 SPB threads
+        if ((int)threadIdx.x >= 4 * SPB) return;
+        const int j = threadIdx.x >> 2, comp = threadIdx.x & 3, uslot = slot0 + j;
+        const int raw = uslot < nslots ? w.agent_of[uslot] : -1;
+        if (raw < 0) return;                             // (the same for the four lanes of a quad)
+        const double *const rj = s_rec + j;
+        const int a = raw & AGENT_MASK;
+        const bool ch2 = (raw & CH2_BIT) != 0;
+        double *psi_out = w.psi_direct ? w.psi_direct + a : !ch2 ? w.rec + (size_t)a * REC + R_PSIE : nullptr;
+        adjoint_rec_quad_kin(c, uslot < sm.gpad, comp, [=](int k, int f) { return rj[(size_t)f * NS + k * SPB]; },
+                             psi_out, (ch2 ? w.ge2 : w.ge) + (size_t)a * c.n);
+        return;
+    }
     if ((int)threadIdx.x >= SPB) return;
     const int j = threadIdx.x, uslot = slot0 + j;
     const int raw = uslot < nslots ? w.agent_of[uslot] : -1;

@@ -137,7 +137,14 @@ __device__ __forceinline__ void solo_eval(const DevCfg &c, const Workspace &w, i
     }
     __builtin_amdgcn_wave_barrier();
     SOLO_CLK(recs, tclk);
-    if (hl == 0 && live) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rc[f * N + k]; });
+    if constexpr (MODEL == KIN) {
+        // (the kinematic adjoint by a quad of lanes: mpc_eval.hpp adjoint_rec_quad_kin -- same bits, a third of the chain)
+        if (hl < 4 && live) {
+            double *psi_out = w.psi_direct ? w.psi_direct + a : !ch2 ? w.rec + (size_t)a * REC + R_PSIE : nullptr;
+            adjoint_rec_quad_kin(c, is_g, hl, [=](int k, int f) { return rc[f * N + k]; }, psi_out,
+                                 (ch2 ? w.ge2 : w.ge) + (size_t)a * n);
+        }
+    } else if (hl == 0 && live) adjoint_rec<MODEL>(c, w, a, ch2, is_g, [=](int k, int f) { return rc[f * N + k]; });
     SOLO_CLK(adj, tclk);
 }
 
