@@ -807,17 +807,19 @@ stage_adjoint_kernel(const DevCfg c, const Workspace w, const int *__restrict__ 
     }
     __syncthreads();
     if constexpr (MODEL == KIN) {
-        // the adjoint recursion by a quad of lanes per request (adjoint_rec_quad_kin): 4 SPB threads
-        if ((int)threadIdx.x >= 4 * SPB) return;
-        const int j = threadIdx.x >> 2, comp = threadIdx.x & 3, uslot = slot0 + j;
-        const int raw = uslot < nslots ? w.agent_of[uslot] : -1;
-        if (raw < 0) return;                             // (the same for the four lanes of a quad)
-        const double *const rj = s_rec + j;
-        const int a = raw & AGENT_MASK;
-        const bool ch2 = (raw & CH2_BIT) != 0;
-        double *psi_out = w.psi_direct ? w.psi_direct + a : !ch2 ? w.rec + (size_t)a * REC + R_PSIE : nullptr;
-        adjoint_rec_quad_kin(c, uslot < sm.gpad, comp, [=](int k, int f) { return rj[(size_t)f * NS + k * SPB]; },
-                             psi_out, (ch2 ? w.ge2 : w.ge) + (size_t)a * c.n);
+        // the adjoint recursion by a quad of lanes per request (adjoint_rec_quad_kin): 4 SPB lanes -- more than the
+        // workgroup has threads when the horizon is shorter than four stages, hence the loop (quads stay aligned: 4 | BLK)
+        for (int t = threadIdx.x; t < 4 * SPB; t += BLK) {
+            const int j = t >> 2, comp = t & 3, uslot = slot0 + j;
+            const int raw = uslot < nslots ? w.agent_of[uslot] : -1;
+            if (raw < 0) continue;                       // (the same for the four lanes of a quad)
+            const double *const rj = s_rec + j;
+            const int a = raw & AGENT_MASK;
+            const bool ch2 = (raw & CH2_BIT) != 0;
+            double *psi_out = w.psi_direct ? w.psi_direct + a : !ch2 ? w.rec + (size_t)a * REC + R_PSIE : nullptr;
+            adjoint_rec_quad_kin(c, uslot < sm.gpad, comp, [=](int k, int f) { return rj[(size_t)f * NS + k * SPB]; },
+                                 psi_out, (ch2 ? w.ge2 : w.ge) + (size_t)a * c.n);
+        }
         return;
     }
     if ((int)threadIdx.x >= SPB) return;

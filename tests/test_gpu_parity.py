@@ -711,7 +711,7 @@ def test_stage_cost_matches_oracle(dev, O, model):
 
 
 # ----------------------------------------------------------------------------- K1
-@pytest.mark.parametrize("model,N,B", [(0, 20, 300), (1, 12, 300), (1, 20, 65), (0, 40, 64), (0, 1, 5),
+@pytest.mark.parametrize("model,N,B", [(0, 20, 300), (1, 12, 300), (1, 20, 65), (0, 40, 64), (0, 1, 5), (0, 1, 700), (0, 3, 500), (0, 2, 333),
                                        (1, 64, 3), (0, 7, 130)])
 def test_cost_and_gradient_match_oracle(dev, O, model, N, B):
     """K1 against the oracle: psi 1e-12 relative, gradient 1e-9 of its norm (fp64, same op order
