@@ -1403,6 +1403,31 @@ def test_full_size_properties(dev):
     assert torch.equal(U2, U)
 
 
+def test_config4_whole_batch_on_one_gpu_is_its_eight_shards(dev):
+    """BASELINE.json configs[3] (524 288 agents over 8 GPUs) as ONE batch on one GPU -- eight times the metric's
+    per-GPU batch through one handle (13 GB of workspace, offsets beyond 2^32 bytes) -- against what ranks 0 and 7 of
+    the sharded job compute from their own rows (bench.py's shard_bounds + block-seeded states): the same bits, so
+    the N-GPU job IS the big batch.  Every agent converges; the controls keep to the box."""
+    import bench
+    from model_predictive_control_amd.sharding import shard_bounds
+    N, B, world = 20, 524288, 8
+    eng = mp.BatchedMPC(mp.default_config(0, N), dev)
+    cl = T(straight_centerline(), dev)
+    X0 = T(bench.synthetic_states(0, 0, B), dev)
+    U0 = torch.tensor([1.0, 0.0], dtype=torch.float64, device=dev).repeat(B, N)
+    U, _, st = eng.solve(X0, cl, U0)
+    assert (st[:, 0] == 1).all() and st[:, 4].max().item() <= 1e-6
+    assert (U[:, 0::2].abs().max() <= 1.0) and (U[:, 1::2].abs().max() <= 0.32)
+    small = mp.BatchedMPC(mp.default_config(0, N), dev)
+    for rank in (0, world - 1):
+        lo, hi = shard_bounds(B, rank, world)
+        assert hi - lo == 65536
+        Xr = T(bench.synthetic_states(0, lo, hi), dev)
+        assert torch.equal(Xr, X0[lo:hi])
+        Ur, _, str_ = small.solve(Xr, cl, U0[:hi - lo].contiguous())
+        assert torch.equal(Ur, U[lo:hi]) and torch.equal(str_[:, :4], st[lo:hi, :4])
+
+
 def test_full_size_pacejka_properties(dev):
     """The reference's own model at full batch size (Pacejka nx = 6, N = 12 as main.py:67-68 runs it,
     B = 65536) with NO evaluation budget: every agent converges, nobody straggles (round 1 needed a
