@@ -136,18 +136,10 @@ __device__ __forceinline__ SinCos m_sincos(double x)
 }
 __device__ __forceinline__ double m_sin(double x) { return m_sincos(x).s; }
 
-// atan of the ratio num/den of two non-negative numbers (not both zero), result in [0, pi/2]
-__device__ __forceinline__ double atan_ratio(double ay, double ax)
+// The polynomial half of atan_ratio: atan(r) + (off_hi + off_lo) for a reduced |r| <= tan(pi/8)
+__device__ __forceinline__ double atan_reduced(double r, double off_hi, double off_lo)
 {
 #pragma clang fp contract(off)   // fixed roundings: the same bits in every kernel this is inlined into
-    // three intervals: r = ay/ax, (ay-ax)/(ay+ax) or -ax/ay, |r| <= tan(pi/8)
-    const bool lo = ay <= 0.41421356237309503 * ax;
-    const bool hi = ay > 2.4142135623730951 * ax;
-    const double num = lo ? ay : (hi ? -ax : ay - ax);
-    const double den = lo ? ax : (hi ? ay : ay + ax);
-    const double r = num / den;
-    const double off_hi = lo ? 0.0 : (hi ? 1.57079632679489655800e+00 : 7.85398163397448278999e-01);
-    const double off_lo = lo ? 0.0 : (hi ? 6.12323399573676603587e-17 : 3.06161699786838301793e-17);
     const double z = r * r, w = z * z;
     double s1 = fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
     s1 = fma(w, s1, 6.66107313738753120669e-02);
@@ -161,9 +153,31 @@ __device__ __forceinline__ double atan_ratio(double ay, double ax)
     return off_hi - ((r * (s1 + s2) - off_lo) - r);
 }
 
+// atan of the ratio num/den of two non-negative numbers (not both zero), result in [0, pi/2]
+__device__ __forceinline__ double atan_ratio(double ay, double ax)
+{
+#pragma clang fp contract(off)   // fixed roundings: the same bits in every kernel this is inlined into
+    // three intervals: r = ay/ax, (ay-ax)/(ay+ax) or -ax/ay, |r| <= tan(pi/8)
+    const bool lo = ay <= 0.41421356237309503 * ax;
+    const bool hi = ay > 2.4142135623730951 * ax;
+    const double num = lo ? ay : (hi ? -ax : ay - ax);
+    const double den = lo ? ax : (hi ? ay : ay + ax);
+    const double r = num / den;
+    const double off_hi = lo ? 0.0 : (hi ? 1.57079632679489655800e+00 : 7.85398163397448278999e-01);
+    const double off_lo = lo ? 0.0 : (hi ? 6.12323399573676603587e-17 : 3.06161699786838301793e-17);
+    return atan_reduced(r, off_hi, off_lo);
+}
+
 MPC_ATAN_FN double m_atan(double x) // leaf
 {
     const double a = fabs(x);
+#ifndef MPC_ATAN_ALWAYS_DIVIDES
+    // Every lane inside atan_ratio(a, 1)'s first interval (the Pacejka axle terms bf alpha_f, br alpha_r always are:
+    // |alpha| < 1.5 rad): its quotient is a / 1.0 = a exactly, so the division -- eleven instructions that hold a SIMD for
+    // ~60 cycles, as long as fourteen fma (tools/micro/fp64_chain.hip) -- is left out.  Same bits; wave-uniform, and a
+    // lane's result does not depend on the path its wave takes.
+    if (__builtin_expect(__ballot(!(a <= 0.41421356237309503)) == 0ull, 1)) return copysign(atan_reduced(a, 0.0, 0.0), x);
+#endif
     const double t = a < 1.0e300 ? atan_ratio(a, 1.0) : 1.57079632679489655800e+00;
     return x != x ? x : copysign(t, x);
 }

@@ -59,6 +59,15 @@ def test_device_math(dev):
     a = eng.math_probe(2, T(t, dev)).cpu().numpy()
     assert _ulps(a[t != 0], np.arctan(t)[t != 0]).max() <= 2.0
     assert np.array_equal(np.signbit(a), np.signbit(t))
+    # m_atan leaves the division out when EVERY lane of the wave is inside the first interval (a / 1.0 = a): the same
+    # bits as the dividing path, which the same values take when one lane of their wave is outside it
+    small = np.concatenate([rng.uniform(-0.41421356237309503, 0.41421356237309503, 64 * 1024 - 4),
+                            [0.0, -0.0, 0.41421356237309503, -0.41421356237309503]])
+    alone = eng.math_probe(2, T(small, dev)).cpu().numpy()
+    mixed = small.reshape(-1, 64).copy(); mixed[:, 63] = 3.0          # lane 63 of every wave leaves the interval
+    other = eng.math_probe(2, T(mixed.ravel(), dev)).cpu().numpy().reshape(-1, 64)
+    assert np.array_equal(alone.reshape(-1, 64)[:, :63].view(np.int64), other[:, :63].view(np.int64))
+    assert _ulps(alone[small != 0], np.arctan(small)[small != 0]).max() <= 2.0
     yy = np.concatenate([rng.standard_normal(200000), rng.uniform(-1e-3, 1e-3, 50000), [0.0, -0.0, 1.0, -1.0, 0.0, 3.0]])
     xx = np.concatenate([rng.standard_normal(200000), rng.uniform(0.2, 2, 50000), [1.0, 1.0, 0.0, 0.0, -2.0, -0.0]])
     g = eng.math_probe(3, T(yy, dev), T(xx, dev)).cpu().numpy()
