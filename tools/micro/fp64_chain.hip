@@ -7,7 +7,7 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <int ILP, int OP>
-__global__ void __launch_bounds__(64) chain(double *out, int iters, double a, double b)
+__global__ void __launch_bounds__(64) chain(double *out, int iters, double a, double b, double one, double nzero)
 {
     double v[ILP];
 #pragma unroll
@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(64) chain(double *out, int iters, double a, do
                 else if (OP == 3) v[i] = b / v[i];                      // the division sequence
                 else if (OP == 4) v[i] = __builtin_amdgcn_rcp(v[i]);    // v_rcp_f64
                 else if (OP == 5) v[i] = v[i] > b ? v[i] * a : v[i] + b; // compare + select + two ops
+                else if (OP == 6) v[i] = __builtin_fma(v[i], one, b);   // v + b as an fma (one = 1.0 at run time: not folded)
+                else if (OP == 7) v[i] = __builtin_fma(v[i], a, nzero); // v * a as an fma (nzero = -0.0 at run time)
             }
         }
     }
@@ -37,10 +39,10 @@ static int run(const char *name, double *d, int blocks, int iters)
 {
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((chain<ILP, OP>), dim3(blocks), dim3(64), 0, 0, d, iters / 10, 0.999999, 1e-7);
+    hipLaunchKernelGGL((chain<ILP, OP>), dim3(blocks), dim3(64), 0, 0, d, iters / 10, 0.999999, 1e-7, 1.0, -0.0);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL((chain<ILP, OP>), dim3(blocks), dim3(64), 0, 0, d, iters, 0.999999, 1e-7);
+    hipLaunchKernelGGL((chain<ILP, OP>), dim3(blocks), dim3(64), 0, 0, d, iters, 0.999999, 1e-7, 1.0, -0.0);
     CHK(hipEventRecord(e1));
     CHK(hipEventSynchronize(e1));
     float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
@@ -69,6 +71,8 @@ int main()
     ROW(3, "div", 10000)
     ROW(4, "rcp", 50000)
     ROW(5, "sel", 50000)
+    ROW(6, "addfma", 100000)
+    ROW(7, "mulfma", 100000)
     CHK(hipFree(d));
     return 0;
 }
